@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors for steps 3-4 by running the REFERENCE itself.
+
+Run in the build container only (it needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference's hawkeye/tracker.py imports cv2 at module level but steps 3-4
+never touch it, so an empty stub module stands in for cv2.
+Nothing from the reference is copied: this script only *calls* it and writes
+inputs + outputs as JSON next to itself.  The detection half (MOG + blob
+detector) lives inside OpenCV, which is not available here, so no golden
+vectors exist for it ("parity unpinned").
+
+Outputs
+  unit_vectors.json      arc geometry, fit_arcs, calculate_weights, tilt,
+                         eval_arc codes on small hand-sized inputs
+  run_<name>.json        full build_initial_arcs -> EM_optimize runs on seeded
+                         synthetic tag sets (inputs included)
+"""
+
+import copy
+import json
+import math
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+sys.path.insert(0, '/root/reference')
+import hawkeye.tracker as ref_tracker            # noqa: E402
+import hawkeye.types as ref_types                # noqa: E402
+
+from hawkeye_amd import synth                    # noqa: E402
+
+import numpy as np                               # noqa: E402
+
+
+def step2_notes(meas, width, height, fps, frame_count):
+    """A notes dict in the state the reference's step 2 leaves behind."""
+    params = ref_tracker.VideoScanner.default_scanner_params()
+    params['min_tags_per_arc'] = (params['min_tags_per_arc_high_fps']
+                                  if fps >= 29 else
+                                  params['min_tags_per_arc_low_fps'])
+    params['max_distance_pixels'] = (params['max_distance_pixels_480'] *
+                                     height / 480)
+    params['radius_window'] = (params['radius_window_high_res']
+                               if height >= 480 else
+                               params['radius_window_low_res'])
+    notes = {
+        'version': 4, 'source': '/nonexistent/synth.mov', 'scanvideo': None,
+        'scanner_params': params, 'step': 2, 'fps': fps,
+        'frame_width': width, 'frame_height': height,
+        'frame_count_estimate': frame_count, 'frame_count': frame_count,
+        'camera_tilt': 0.0, 'meas': {},
+    }
+    for f in range(frame_count):
+        notes['meas'][f] = [ref_types.Balltag(f, x, y, d, 1.0)
+                            for (x, y, d) in meas.get(f, ())]
+    return notes
+
+
+def make_scanner(notes):
+    sc = ref_tracker.VideoScanner('/nonexistent/synth.mov', notes=notes)
+    sc._callback = None
+    sc._verbosity = 0
+    return sc
+
+
+def arc_dict(arc):
+    return {'a': arc.a, 'b': arc.b, 'c': arc.c, 'e': arc.e,
+            'f_peak': arc.f_peak, 'id': arc.id_}
+
+
+def tag_index_map(notes_meas_snapshot):
+    """id(tag) -> (frame, position in the ORIGINAL per-frame list)."""
+    idx = {}
+    for f, lst in notes_meas_snapshot.items():
+        for k, t in enumerate(lst):
+            idx[id(t)] = (f, k)
+    return idx
+
+
+# ---------------------------------------------------------------------------
+# full runs
+# ---------------------------------------------------------------------------
+
+RUNS = {
+    # name: (width, height, fps, balls, frames, scene_seed, tag_seed,
+    #        clutter/frame, tilt_deg)
+    'clean_720p30_5ball': (1280, 720, 30.0, 5, 240, 1001, 11, 3.0, 0.0),
+    'noisy_1080p60_9ball': (1920, 1080, 60.0, 9, 240, 1002, 12, 12.0, 0.0),
+    'tilt3_720p30_5ball': (1280, 720, 30.0, 5, 200, 1004, 14, 4.0, 3.0),
+    'lowfps_480p24_3ball': (640, 480, 24.0, 3, 192, 1005, 15, 2.0, 0.0),
+}
+
+
+def full_run(name, spec):
+    width, height, fps, balls, frames, sseed, tseed, clutter, tilt = spec
+    scene = synth.JugglingScene(width, height, fps, balls, frames, sseed,
+                                tilt_deg=tilt)
+    meas = synth.make_tags(scene, tseed, clutter_per_frame=clutter)
+    notes = step2_notes(meas, width, height, fps, frames)
+    orig = {f: list(lst) for f, lst in notes['meas'].items()}
+    idx = tag_index_map(orig)
+    sc = make_scanner(notes)
+
+    sc.process(steps=(3, 3))
+    step3 = {
+        'g_px_per_frame_sq': notes['g_px_per_frame_sq'],
+        'cm_per_pixel': notes['cm_per_pixel'],
+        'arcs': [dict(arc_dict(a),
+                      tags=sorted(idx[id(t)] for t in a.tags))
+                 for a in notes['arcs']],
+    }
+
+    sc.process(steps=(4, 4))
+    arc_id = {id(a): k for k, a in enumerate(notes['arcs'])}
+    final_assign = []
+    for f in range(frames):
+        for t in notes['meas'][f]:
+            fr, k = idx[id(t)]
+            final_assign.append([fr, k, arc_id[id(t.arc)]])
+    step4 = {
+        'camera_tilt': notes['camera_tilt'],
+        'arcs': [arc_dict(a) for a in notes['arcs']],
+        'assign': final_assign,         # [frame, index-in-input-frame, arc#]
+        'tags_remaining': len(final_assign),
+    }
+
+    out = {
+        'name': name,
+        'width': width, 'height': height, 'fps': fps, 'frames': frames,
+        'generator': {'balls': balls, 'scene_seed': sseed, 'tag_seed': tseed,
+                      'clutter_per_frame': clutter, 'tilt_deg': tilt},
+        'meas': {str(f): [list(t) for t in meas[f]] for f in range(frames)},
+        'step3': step3,
+        'step4': step4,
+    }
+    path = os.path.join(HERE, 'run_{}.json'.format(name))
+    with open(path, 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('{}: {} tags, {} arcs after step 3, {} after step 4 -> {}'.format(
+        name, sum(len(v) for v in meas.values()), len(step3['arcs']),
+        len(step4['arcs']), os.path.basename(path)))
+
+
+# ---------------------------------------------------------------------------
+# unit vectors
+# ---------------------------------------------------------------------------
+
+def unit_vectors():
+    rng = np.random.RandomState(77)
+    out = {}
+
+    # (1) arc geometry -----------------------------------------------------
+    geo = []
+    grid = [
+        # a, b, c, e, f_peak, tilt
+        (640.0, 3.5, 120.0, 0.49, 100.25, 0.0),
+        (640.0, -2.25, 80.0, 0.30, 55.5, 0.02),
+        (200.0, 0.0, 300.0, 0.75, 12.0, 0.0),           # b == 0
+        (900.0, 5.0, 700.0, -0.4, 40.0, 0.0),           # e < 0
+        (100.0, 1.0, 900.0, 0.5, 30.0, -0.05),          # (H-c)/e < 0
+        (1500.0, -7.75, 40.0, 1.1, 400.0, 0.052),
+    ]
+    for (a, b, c, e, fp, tilt) in grid:
+        notes = {'frame_width': 1280, 'frame_height': 720,
+                 'frame_count': 450, 'camera_tilt': tilt}
+        arc = ref_types.Ballarc()
+        arc.a, arc.b, arc.c, arc.e, arc.f_peak = a, b, c, e, fp
+        frames = [0, 7, int(fp), int(fp) + 13, 449]
+        tag = ref_types.Balltag(int(fp) + 3, a + 11.0, c - 4.5, 16.0)
+        geo.append({
+            'params': [a, b, c, e, fp], 'tilt': tilt,
+            'notes': {k: notes[k] for k in ('frame_width', 'frame_height',
+                                            'frame_count')},
+            'frames': frames,
+            'positions': [list(arc.get_position(f, notes)) for f in frames],
+            'frame_range': list(arc.get_frame_range(notes)),
+            'tag': [tag.frame, tag.x, tag.y],
+            'tag_distance': arc.get_distance_from_tag(tag, notes),
+        })
+    out['geometry'] = geo
+
+    # (2) fit_arcs ---------------------------------------------------------
+    fits = []
+    for case in range(6):
+        n = [12, 30, 3, 2, 8, 20][case]
+        tilt = [0.0, 0.03, 0.0, 0.0, -0.02, 0.0][case]
+        e_true, fp_true = 0.45 + 0.1 * case, 50.0 + 3.3 * case
+        frames = sorted(rng.choice(np.arange(int(fp_true) - 25,
+                                             int(fp_true) + 25), n,
+                                   replace=False).tolist())
+        tags = []
+        for f in frames:
+            t = f - fp_true
+            tags.append([int(f), 400.0 + 2.5 * t + rng.normal(0, 0.5),
+                         150.0 + e_true * t * t + rng.normal(0, 0.5),
+                         float(rng.uniform(0.2, 1.0))])
+        if case == 4:
+            # every tag in the same frame: singular normal equations
+            for t in tags:
+                t[0] = int(fp_true)
+        notes = step2_notes({}, 1280, 720, 30.0, 200)
+        notes['camera_tilt'] = tilt
+        sc = make_scanner(notes)
+        arc = ref_types.Ballarc()
+        arc.f_peak, arc.a, arc.b, arc.c, arc.e = (fp_true + 1.7, 1.0, 2.0,
+                                                  3.0, 0.4)
+        start = [arc.a, arc.b, arc.c, arc.e, arc.f_peak]
+        for (f, x, y, w) in tags:
+            t = ref_types.Balltag(f, x, y, 16.0)
+            t.weight = {arc: w}
+            arc.tags.add(t)
+        sc.fit_arcs([arc])
+        fits.append({'tags': tags, 'tilt': tilt, 'start': start,
+                     'result': [arc.a, arc.b, arc.c, arc.e, arc.f_peak]})
+    out['fit_arcs'] = fits
+
+    # (3)+(4)+(5) E-step, tilt and eval_arc on a small scene ----------------
+    scene = synth.JugglingScene(1280, 720, 30.0, 3, 90, 31, tilt_deg=2.0)
+    meas = synth.make_tags(scene, 32, clutter_per_frame=2.0)
+    notes = step2_notes(meas, 1280, 720, 30.0, 90)
+    orig = {f: list(lst) for f, lst in notes['meas'].items()}
+    idx = tag_index_map(orig)
+    sc = make_scanner(notes)
+    sc.process(steps=(3, 3))
+    arcs = notes['arcs']
+    pre = [dict(arc_dict(a), tags=sorted(idx[id(t)] for t in a.tags))
+           for a in arcs]
+    sc.estimate_camera_tilt(arcs)
+    tilt_after = notes['camera_tilt']
+    sc.fit_arcs(arcs)
+    fitted = [arc_dict(a) for a in arcs]
+    sc.calculate_weights(arcs)
+    arc_no = {id(a): k for k, a in enumerate(arcs)}
+    weights = []
+    for f in range(90):
+        for t in orig[f]:
+            for a, w in t.weight.items():
+                weights.append([f, idx[id(t)][1], arc_no[id(a)], w])
+    members = [sorted(idx[id(t)] for t in a.tags) for a in arcs]
+    codes = [[sc.eval_arc(a, requirepeak=False),
+              sc.eval_arc(a, requirepeak=True)] for a in arcs]
+    # a few hand-made failing arcs for the other codes
+    bad = []
+    nan_arc = ref_types.Ballarc()
+    nan_arc.a = float('nan')
+    bad.append(['nan', sc.eval_arc(nan_arc)])
+    empty = ref_types.Ballarc()
+    empty.e = 0.5
+    bad.append(['empty', sc.eval_arc(empty)])
+    up = copy.copy(arcs[0])
+    up.e = -arcs[0].e
+    bad.append(['neg_accel', sc.eval_arc(up)])
+    weak = copy.copy(arcs[0])
+    weak.e = arcs[0].e * 0.5
+    bad.append(['half_accel', sc.eval_arc(weak)])
+    far = copy.copy(arcs[0])
+    far.a = arcs[0].a + 500.0
+    bad.append(['shifted', sc.eval_arc(far)])
+    nopeak = copy.copy(arcs[0])
+    nopeak.f_peak = arcs[0].f_peak + 500.0
+    bad.append(['no_peak', sc.eval_arc(nopeak, requirepeak=True,
+                                       checkaccel=False)])
+    out['estep'] = {
+        'width': 1280, 'height': 720, 'fps': 30.0, 'frames': 90,
+        'meas': {str(f): [list(t) for t in meas[f]] for f in range(90)},
+        'g_px_per_frame_sq': notes['g_px_per_frame_sq'],
+        'arcs_after_step3': pre,
+        'camera_tilt': tilt_after,
+        'arcs_after_fit': fitted,
+        'weights': weights,
+        'members': members,
+        'eval_codes': codes,
+        'bad_arc_codes': bad,
+    }
+
+    with open(os.path.join(HERE, 'unit_vectors.json'), 'w') as fh:
+        json.dump(out, fh, separators=(',', ':'))
+    print('unit_vectors.json written: {} geometry, {} fits, {} weights'.format(
+        len(geo), len(fits), len(weights)))
+
+
+if __name__ == '__main__':
+    unit_vectors()
+    for name, spec in RUNS.items():
+        full_run(name, spec)
