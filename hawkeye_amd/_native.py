@@ -1,0 +1,73 @@
+"""
+ctypes binding of libhawkeye_hip.so (C ABI declared in include/hk.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C
+hawkeye_amd/csrc``).  There is no fallback: if the shared object is missing or
+does not load, importing this module raises, and every product entry point
+that needs it fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhawkeye_hip.so')
+
+
+class NativeError(RuntimeError):
+    """A libhawkeye_hip call returned a negative status."""
+
+    def __init__(self, status, message):
+        super().__init__('libhawkeye_hip error {}: {}'.format(status, message))
+        self.status = status
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            '{} not found: build it with `python -c "import __graft_entry__ '
+            'as g; g.build()"` or `make -C hawkeye_amd/csrc`; there is no '
+            'CPU fallback'.format(LIB_PATH))
+    # PyTorch-ROCm ships its own libamdhip64.so.7; import it first so that
+    # this library binds to the same HIP runtime instance and device pointers
+    # of torch tensors are valid here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+def _sig(name, argtypes, restype=C.c_int):
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_sig('hk_last_error', [], C.c_char_p)
+_sig('hk_version', [])
+_sig('hk_device_count', [])
+
+_sig('hk_mog_create', [C.c_int, C.c_int, C.c_int, c_void_pp])
+_sig('hk_mog_destroy', [C.c_void_p])
+_sig('hk_mog_reset', [C.c_void_p, C.c_void_p])
+_sig('hk_mog_nframes', [C.c_void_p])
+_sig('hk_mog_apply', [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                      C.c_void_p])
+_sig('hk_mog_apply_batch', [C.c_void_p, C.c_void_p, C.c_long, C.c_long,
+                            C.c_void_p, C.c_long, C.c_long, C.c_int,
+                            C.c_void_p])
+_sig('hk_mog_export_model', [C.c_void_p, C.c_void_p, C.c_void_p])
+
+
+def check(status):
+    """Raise NativeError for a negative status, else return the status."""
+    if status < 0:
+        raise NativeError(status, lib.hk_last_error().decode('utf-8',
+                                                             'replace'))
+    return status

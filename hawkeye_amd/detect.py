@@ -1,0 +1,96 @@
+"""
+Host-side mirror of the two OpenCV objects the reference's step 2 uses
+(reference tracker.py:357-396), over device-resident frames.
+
+    fgbg = cv2.bgsegm.createBackgroundSubtractorMOG()  ->  BackgroundSubtractorMOG
+    fgmask = fgbg.apply(frame)                         ->  .apply(frame)
+
+Frames and masks are PyTorch-ROCm uint8 tensors (plumbing only: device memory
+and the current HIP stream); all arithmetic happens in libhawkeye_hip.so.
+"""
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class BackgroundSubtractorMOG:
+    """KaewTraKulPong-Bowden mixture model with OpenCV's default parameters
+    (history 200, 5 mixtures, backgroundRatio 0.7, noiseSigma 15), i.e. what
+    ``cv2.bgsegm.createBackgroundSubtractorMOG()`` builds."""
+
+    def __init__(self, width, height, device=0):
+        self.width, self.height = int(width), int(height)
+        self.device = torch.device('cuda', device)
+        h = nat.C.c_void_p()
+        nat.check(nat.lib.hk_mog_create(self.width, self.height, device,
+                                        nat.C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            nat.lib.hk_mog_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def nframes(self):
+        return nat.lib.hk_mog_nframes(self._h)
+
+    def reset(self):
+        nat.check(nat.lib.hk_mog_reset(self._h, _stream_ptr(self.device)))
+
+    def _as_device_frames(self, frames):
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        if frames.dtype != torch.uint8:
+            raise TypeError('frames must be uint8 BGR')
+        if frames.device != self.device:
+            frames = frames.to(self.device)
+        return frames
+
+    def apply(self, frame, out=None):
+        """One BGR frame [H][W][3] -> foreground mask [H][W] of {0, 255}."""
+        frame = self._as_device_frames(frame)
+        if tuple(frame.shape) != (self.height, self.width, 3):
+            raise ValueError('frame shape {} != ({}, {}, 3)'.format(
+                tuple(frame.shape), self.height, self.width))
+        return self.apply_batch(frame.unsqueeze(0),
+                                None if out is None else out.unsqueeze(0))[0]
+
+    def apply_batch(self, frames, out=None):
+        """Frames [T][H][W][3] -> masks [T][H][W]; identical to T apply()
+        calls, in one launch with the model held in registers."""
+        frames = self._as_device_frames(frames)
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (
+                self.height, self.width, 3):
+            raise ValueError('frames shape {} != (T, {}, {}, 3)'.format(
+                tuple(frames.shape), self.height, self.width))
+        if frames.stride(3) != 1 or frames.stride(2) != 3:
+            frames = frames.contiguous()
+        t = frames.shape[0]
+        if out is None:
+            out = torch.empty((t, self.height, self.width), dtype=torch.uint8,
+                              device=self.device)
+        elif (out.dtype != torch.uint8 or out.device != self.device or
+              tuple(out.shape) != (t, self.height, self.width) or
+              out.stride(2) != 1):
+            raise ValueError('bad `out` tensor')
+        nat.check(nat.lib.hk_mog_apply_batch(
+            self._h, frames.data_ptr(), frames.stride(0), frames.stride(1),
+            out.data_ptr(), out.stride(0), out.stride(1), t,
+            _stream_ptr(self.device)))
+        return out
+
+    def export_model(self):
+        """Mixture model as float32 [H*W][5][8] in OpenCV's MixData order
+        (sortKey, weight, mean[3], var[3]); for parity tests."""
+        out = np.empty((self.height * self.width, 5, 8), np.float32)
+        nat.check(nat.lib.hk_mog_export_model(self._h, out.ctypes.data,
+                                              _stream_ptr(self.device)))
+        return out

@@ -1,0 +1,89 @@
+/*
+ * hk.h -- C ABI of libhawkeye_hip.so, the MI355X (gfx950) implementation of
+ * Hawkeye's detection + arc-fitting hot path.
+ *
+ * The reference (jkboyce/hawkeye) has no FFI of its own: the boundary of the
+ * hot path is the Python class API of hawkeye/tracker.py.  Each entry point
+ * below therefore cites the reference call site whose arithmetic it replaces;
+ * hawkeye_amd/tracker.py binds them with ctypes and keeps the reference's
+ * Python surface on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative hk_status on error;
+ *     hk_last_error() then returns a thread-local description.  No C++
+ *     exception crosses this boundary.
+ *   - "dev" pointers are device (HBM) addresses on the device the handle was
+ *     created for; "host" pointers are ordinary host memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *     Functions that only enqueue work say so; the others synchronise the
+ *     stream before returning host results.
+ *   - handles are not thread safe; use one host thread per handle (the
+ *     reference drives the scanner from a single worker thread,
+ *     reference worker.py:718-778).
+ */
+#ifndef HK_H
+#define HK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum hk_status {
+    HK_OK = 0,
+    HK_ERR_ARG = -1,        /* bad argument / unsupported shape */
+    HK_ERR_HIP = -2,        /* a HIP runtime call failed */
+    HK_ERR_CAPACITY = -3,   /* an output or work list overflowed its capacity */
+    HK_ERR_ALLOC = -4,
+    HK_ERR_ABORTED = -5,    /* progress callback asked to stop */
+    HK_ERR_INTERNAL = -6
+};
+
+const char *hk_last_error(void);
+int hk_version(void);
+
+/* Number of HIP devices visible, or a negative status. */
+int hk_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * K1  MOG background subtraction
+ *     replaces cv2.bgsegm.createBackgroundSubtractorMOG()  (reference
+ *     tracker.py:357) and fgbg.apply(frame)                 (tracker.py:395)
+ *     with OpenCV's default parameters: history 200, 5 mixtures,
+ *     backgroundRatio 0.7, noiseSigma 15, learning rate 1/min(n, 200).
+ * ---------------------------------------------------------------------- */
+typedef struct hk_mog hk_mog;
+
+/* Allocates the zero-initialised mixture model for width x height BGR frames
+ * (40 fp32 planes of width*height, SoA) on `device`. */
+int hk_mog_create(int width, int height, int device, hk_mog **out);
+int hk_mog_destroy(hk_mog *m);
+/* Back to the freshly created state (model zero, frame counter 0).  Enqueues. */
+int hk_mog_reset(hk_mog *m, void *stream);
+/* Frames applied so far. */
+int hk_mog_nframes(const hk_mog *m);
+
+/* One frame, = fgmask = fgbg.apply(frame).  bgr_dev: uint8 [H][bgr_pitch]
+ * with 3 bytes per pixel; mask_dev: uint8 [H][mask_pitch], written with
+ * {0, 255}.  Enqueues on `stream`. */
+int hk_mog_apply(hk_mog *m, const void *bgr_dev, long bgr_pitch,
+                 void *mask_dev, long mask_pitch, void *stream);
+
+/* `nframes` consecutive frames in one launch; results are identical to
+ * nframes calls of hk_mog_apply.  The model of each pixel stays in registers
+ * for the whole batch, so HBM traffic is ~4 B/pixel/frame instead of 324.
+ * Frame t is at bgr_dev + t*bgr_frame_stride (bytes), mask t at
+ * mask_dev + t*mask_frame_stride.  Enqueues on `stream`. */
+int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
+                       long bgr_pitch, void *mask_dev, long mask_frame_stride,
+                       long mask_pitch, int nframes, void *stream);
+
+/* Copies the model to host in OpenCV's AoS order: float [H*W][5][8] =
+ * (sortKey, weight, mean[3], var[3]).  For tests.  Synchronises. */
+int hk_mog_export_model(hk_mog *m, float *host_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HK_H */
