@@ -65,6 +65,34 @@ _sig('hk_mog_apply_batch', [C.c_void_p, C.c_void_p, C.c_long, C.c_long,
 _sig('hk_mog_export_model', [C.c_void_p, C.c_void_p, C.c_void_p])
 
 
+class BlobParams(C.Structure):
+    """hk_blob_params (include/hk.h); field names follow
+    cv2.SimpleBlobDetector_Params."""
+    _fields_ = [('thresholdStep', C.c_float), ('minThreshold', C.c_float),
+                ('maxThreshold', C.c_float), ('minRepeatability', C.c_int),
+                ('minDistBetweenBlobs', C.c_float), ('filterByColor', C.c_int),
+                ('blobColor', C.c_int), ('filterByArea', C.c_int),
+                ('minArea', C.c_float), ('maxArea', C.c_float),
+                ('filterByCircularity', C.c_int),
+                ('minCircularity', C.c_float), ('maxCircularity', C.c_float),
+                ('filterByInertia', C.c_int), ('filterByConvexity', C.c_int)]
+
+
+_sig('hk_blob_params_hawkeye', [C.POINTER(BlobParams), C.c_int])
+_sig('hk_blob_create', [C.c_int, C.c_int, C.c_int, C.POINTER(BlobParams),
+                        C.c_int, c_void_pp])
+_sig('hk_blob_destroy', [C.c_void_p])
+_sig('hk_blob_enqueue', [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                         C.c_void_p])
+_sig('hk_blob_finish', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                        C.POINTER(C.c_int)])
+_sig('hk_blob_detect', [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                        C.POINTER(C.c_int)])
+_sig('hk_blob_finish_centers', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.POINTER(C.c_int)])
+
+
 def check(status):
     """Raise NativeError for a negative status, else return the status."""
     if status < 0:

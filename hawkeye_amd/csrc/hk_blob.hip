@@ -1,0 +1,728 @@
+// K2-K4 -- SimpleBlobDetector on binary masks for gfx950.
+//
+// Replaces detector.detect(fgmask) (reference tracker.py:396; arithmetic in
+// OpenCV's blobdetector.cpp / contours.cpp / moments.cpp / shapedescr.cpp,
+// restated in oracle/detect_ref.c).
+//
+// OpenCV finds borders with a sequential raster scan that marks pixels as it
+// traces, so that every border is followed exactly once.  Here the same set
+// of borders is found without marks:
+//
+//   K2 blob_scan_k   reads each mask byte once (16 B per lane, HBM-bound) and
+//                    emits *candidate* border starts: a foreground pixel
+//                    whose W, NW, N, NE neighbours are background (possible
+//                    raster-first pixel of an 8-connected component), or a
+//                    background pixel whose W and N neighbours are
+//                    foreground (possible raster-first pixel of a 4-connected
+//                    hole).  Wave-level ballot/prefix compaction, one atomic
+//                    per wave.
+//   K3 blob_trace_k  one lane per candidate follows the border exactly as
+//                    icvFetchContour does (same start direction, same sweep
+//                    order), accumulating the integer Green sums and
+//                    straight/diagonal step counts.  A candidate is the real
+//                    start iff nothing on its border lies before it in raster
+//                    order; other candidates retire.  The area and
+//                    circularity filters bound the useful contour length
+//                    (perimeter^2 <= 4 pi maxArea / minCircularity), so the
+//                    trace is cut there.  Survivors get their centroid
+//                    (double), pass the colour test and store their points.
+//   K3b blob_radius_k one wave per surviving contour selects the two middle
+//                    order statistics of the squared centre-to-point
+//                    distances (rank counting in LDS).
+//   K4 (host)        orders contours as findContours(RETR_LIST) returns them,
+//                    takes the square roots, replays the cross-threshold
+//                    grouping loop of SimpleBlobDetector::detect and emits
+//                    float32 keypoints.
+//
+// All integer work is exact; the few double operations are IEEE and
+// uncontracted, so results equal the oracle's bit for bit.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "hk_common.h"
+
+namespace {
+
+constexpr int MAXPTS = 256;             // hard cap on a traced contour
+constexpr int CTR_NCAND = 0, CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
+constexpr unsigned FLAG_NONBINARY = 1u;
+
+struct Cand {
+    uint32_t pos;           // (y << 16) | x of the start (foreground) pixel
+    uint32_t fh;            // (frame << 1) | is_hole
+};
+
+struct BlobRec {
+    int32_t frame;
+    uint32_t key;           // (y << 16) | x where the raster scan finds it
+    int32_t is_hole;
+    int32_t npts;
+    long long a00, a10, a01;
+    double cx, cy;
+    double d2lo, d2hi;      // middle order statistics of squared distances
+};
+
+struct DevParams {
+    int filterByColor, blobColor;
+    double minArea, maxArea, minCirc, maxCirc;
+    int max_pts;
+};
+
+__device__ __forceinline__ int dir_dx(int s) {
+    return (int)((0x901Au >> (2 * s)) & 3u) - 1;    // E NE N NW W SW S SE
+}
+__device__ __forceinline__ int dir_dy(int s) {
+    return (int)((0xA901u >> (2 * s)) & 3u) - 1;
+}
+
+// top bits of 4 bytes -> 4 bits, byte 0 -> bit 0
+__device__ __forceinline__ unsigned top_bits(unsigned w) {
+    return ((((w >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+__device__ __forceinline__ bool not_binary(unsigned w) {
+    const unsigned hi = (w >> 7) & 0x01010101u;
+    return (w & 0x7F7F7F7Fu) != hi * 0x7Fu;
+}
+
+// Foreground bits of pixels x0 .. x0+15 of one row (bit i = pixel x0+i);
+// pixels outside [0, W) read as background.
+__device__ __forceinline__ unsigned row_bits16(const uint8_t *row, int x0,
+                                               int W, bool vec,
+                                               bool &nonbinary) {
+    if (row == nullptr) return 0u;
+    if (vec && x0 + 16 <= W) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + x0);
+        nonbinary |= not_binary(v.x) || not_binary(v.y) || not_binary(v.z) ||
+                     not_binary(v.w);
+        return top_bits(v.x) | (top_bits(v.y) << 4) | (top_bits(v.z) << 8) |
+               (top_bits(v.w) << 12);
+    }
+    unsigned bits = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int x = x0 + i;
+        if (x < W) {
+            const unsigned b = row[x];
+            nonbinary |= (b != 0u && b != 255u);
+            bits |= (b >> 7) << i;
+        }
+    }
+    return bits;
+}
+__device__ __forceinline__ unsigned row_bit(const uint8_t *row, int x, int W) {
+    return (row != nullptr && x >= 0 && x < W) ? (unsigned)(row[x] >> 7) : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// K2
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blob_scan_k(
+    const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
+    int H, int nframes, int segs, bool vec, Cand *__restrict__ cands,
+    unsigned *__restrict__ ctr, unsigned cap_cand) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)nframes * H * segs;
+    unsigned outer = 0, hole = 0;
+    int f = 0, y = 0, x0 = 0;
+    bool nonbinary = false;
+    if (tid < total) {
+        const int seg = (int)(tid % segs);
+        const long rowid = tid / segs;
+        y = (int)(rowid % H);
+        f = (int)(rowid / H);
+        x0 = seg * 16;
+        const uint8_t *row = masks + (long)f * frame_stride + (long)y * pitch;
+        const uint8_t *prow = y > 0 ? row - pitch : nullptr;
+        // bit j of cur17 / up18 = pixel x0 - 1 + j
+        const unsigned cur17 = (row_bits16(row, x0, W, vec, nonbinary) << 1) |
+                               row_bit(row, x0 - 1, W);
+        bool dummy = false;
+        const unsigned up18 = (row_bits16(prow, x0, W, vec, dummy) << 1) |
+                              row_bit(prow, x0 - 1, W) |
+                              (row_bit(prow, x0 + 16, W) << 17);
+        const int nvalid = W - x0 < 16 ? W - x0 : 16;
+        const unsigned valid = (1u << nvalid) - 1u;
+        outer = (cur17 >> 1) & ~cur17 & ~up18 & ~(up18 >> 1) & ~(up18 >> 2) &
+                valid;
+        hole = ~(cur17 >> 1) & cur17 & (up18 >> 1) & valid;
+    }
+    if (nonbinary) atomicOr(&ctr[CTR_FLAGS], FLAG_NONBINARY);
+
+    const unsigned c = __popc(outer) + __popc(hole);
+    if (__ballot(c != 0) == 0ull) return;       // wave-uniform
+
+    // inclusive prefix sum of c over the wave
+    const int lane = threadIdx.x & 63;
+    unsigned incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const unsigned wave_total = __shfl(incl, 63, 64);
+    unsigned base = 0;
+    if (lane == 63) base = atomicAdd(&ctr[CTR_NCAND], wave_total);
+    base = __shfl(base, 63, 64);
+    unsigned at = base + incl - c;
+    while (outer) {
+        const int i = __ffs(outer) - 1;
+        outer &= outer - 1;
+        if (at < cap_cand)
+            cands[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i),
+                             (unsigned)f << 1};
+        ++at;
+    }
+    while (hole) {
+        const int i = __ffs(hole) - 1;
+        hole &= hole - 1;
+        if (at < cap_cand)      // origin = the foreground pixel left of it
+            cands[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
+                             ((unsigned)f << 1) | 1u};
+        ++at;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3
+// ---------------------------------------------------------------------------
+struct Img {
+    const uint8_t *p;
+    long pitch;
+    int W, H;
+    __device__ __forceinline__ unsigned fg(int x, int y) const {
+        return (x >= 0 && x < W && y >= 0 && y < H)
+                   ? (unsigned)(p[(long)y * pitch + x] != 0)
+                   : 0u;
+    }
+    __device__ __forceinline__ unsigned ring(int x, int y) const {
+        unsigned m = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            m |= fg(x + dir_dx(d), y + dir_dy(d)) << d;
+        return m;
+    }
+};
+
+struct Trace {
+    long long a00, a10, a01;
+    int ns, nd, npts;
+    bool valid;
+};
+
+__device__ __forceinline__ bool before(int x, int y, int rx, int ry) {
+    return y < ry || (y == ry && x < rx);
+}
+
+// Border following from the foreground pixel (x0, y0), icvFetchContour order.
+// `hole` selects the start direction.  A trace is valid iff it closes within
+// max_pts points and (outer) visits no pixel before (x0, y0) in raster order
+// / (hole) examines no background pixel before (x0 + 1, y0).
+template <bool WRITE>
+__device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
+                               int max_pts, ushort2 *__restrict__ pts) {
+    Trace t{0, 0, 0, 0, 0, 0, false};
+    const int rx = hole ? x0 + 1 : x0, ry = y0;
+    const int s0 = hole ? 0 : 4;
+
+    unsigned nb = img.ring(x0, y0);
+    if (nb == 0u) {                     // single pixel domain
+        if (WRITE) pts[0] = make_ushort2((unsigned short)x0, (unsigned short)y0);
+        t.npts = 1;
+        t.valid = !hole;
+        return t;
+    }
+    // first neighbour clockwise from s0 (directions s0-1, s0-2, ...)
+    int s = s0;
+    for (int j = 1; j < 8; ++j) {
+        s = (s0 - j) & 7;
+        if ((nb >> s) & 1u) break;
+        if (hole && before(x0 + dir_dx(s), y0 + dir_dy(s), rx, ry)) return t;
+    }
+    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+
+    int x3 = x0, y3 = y0;
+    for (;;) {
+        // sweep counter-clockwise from s + 1 to the next foreground pixel
+        const int first = (s + 1) & 7;
+        const unsigned rot = ((nb | (nb << 8)) >> first) & 0xFFu;
+        const int skip = __ffs(rot) - 1;            // rot != 0 always
+        if (hole) {
+            for (int j = 0; j < skip; ++j) {
+                const int d = (first + j) & 7;
+                if (before(x3 + dir_dx(d), y3 + dir_dy(d), rx, ry)) return t;
+            }
+        }
+        s = (first + skip) & 7;
+        const int x4 = x3 + dir_dx(s), y4 = y3 + dir_dy(s);
+
+        if (!hole && before(x3, y3, rx, ry)) return t;
+        if (t.npts >= max_pts) return t;
+        if (WRITE) pts[t.npts] = make_ushort2((unsigned short)x3, (unsigned short)y3);
+        ++t.npts;
+        if (s & 1) ++t.nd; else ++t.ns;
+        const long long dxy = (long long)x3 * y4 - (long long)x4 * y3;
+        t.a00 += dxy;
+        t.a10 += dxy * (x3 + x4);
+        t.a01 += dxy * (y3 + y4);
+
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
+        x3 = x4;
+        y3 = y4;
+        s = (s + 4) & 7;
+        nb = img.ring(x3, y3);
+    }
+    t.valid = true;
+    return t;
+}
+
+__global__ __launch_bounds__(64) void blob_trace_k(
+    const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
+    int H, const Cand *__restrict__ cands, unsigned *__restrict__ ctr,
+    unsigned cap_cand, BlobRec *__restrict__ recs, ushort2 *__restrict__ pts,
+    unsigned cap_blob, const DevParams prm) {
+    unsigned n = ctr[CTR_NCAND];
+    if (n > cap_cand) n = cap_cand;
+    for (unsigned i = blockIdx.x * 64u + threadIdx.x; i < n;
+         i += gridDim.x * 64u) {
+        const Cand c = cands[i];
+        const int x0 = (int)(c.pos & 0xFFFFu), y0 = (int)(c.pos >> 16);
+        const int frame = (int)(c.fh >> 1);
+        const bool hole = (c.fh & 1u) != 0u;
+        const Img img{masks + (long)frame * frame_stride, pitch, W, H};
+
+        const Trace t = follow_border<false>(img, x0, y0, hole, prm.max_pts,
+                                             nullptr);
+        if (!t.valid) continue;
+
+        // contourMoments(): m00, m10, m01 from the Green sums
+        double m00 = 0.0, m10 = 0.0, m01 = 0.0;
+        if (t.a00 != 0) {
+            const double h = t.a00 > 0 ? 0.5 : -0.5;
+            const double sixth = t.a00 > 0
+                                     ? 0.16666666666666666666666666666667
+                                     : -0.16666666666666666666666666666667;
+            m00 = (double)t.a00 * h;
+            m10 = (double)t.a10 * sixth;
+            m01 = (double)t.a01 * sixth;
+        }
+        const double area = m00;
+        if (area < prm.minArea || area >= prm.maxArea) continue;
+        // arcLength: every segment is 1.0f or sqrtf(2.0f), summed in double
+        const double perimeter =
+            (double)t.ns + (double)t.nd * (double)1.41421354f;
+        const double ratio =
+            4 * 3.1415926535897932384626433832795 * area /
+            (perimeter * perimeter);
+        if (ratio < prm.minCirc || ratio >= prm.maxCirc) continue;
+        if (m00 == 0.0) continue;
+        const double cx = m10 / m00, cy = m01 / m00;
+        if (prm.filterByColor) {
+            const int px = __double2int_rn(cx), py = __double2int_rn(cy);
+            const int v = img.fg(px, py) ? 255 : 0;
+            if (v != prm.blobColor) continue;
+        }
+
+        const unsigned slot = atomicAdd(&ctr[CTR_NBLOB], 1u);
+        if (slot >= cap_blob) continue;         // host reports the overflow
+        BlobRec r;
+        r.frame = frame;
+        r.key = ((unsigned)y0 << 16) | (unsigned)(hole ? x0 + 1 : x0);
+        r.is_hole = hole ? 1 : 0;
+        r.npts = t.npts;
+        r.a00 = t.a00;
+        r.a10 = t.a10;
+        r.a01 = t.a01;
+        r.cx = cx;
+        r.cy = cy;
+        r.d2lo = r.d2hi = 0.0;
+        recs[slot] = r;
+        (void)follow_border<true>(img, x0, y0, hole, prm.max_pts,
+                                  pts + (size_t)slot * MAXPTS);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3b
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void blob_radius_k(
+    const unsigned *__restrict__ ctr, unsigned cap_blob,
+    BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts) {
+    __shared__ double d2[MAXPTS];
+    unsigned n = ctr[CTR_NBLOB];
+    if (n > cap_blob) n = cap_blob;
+    const int lane = threadIdx.x;
+    for (unsigned slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        const int m = recs[slot].npts;
+        const double cx = recs[slot].cx, cy = recs[slot].cy;
+        for (int i = lane; i < m; i += 64) {
+            const ushort2 p = pts[(size_t)slot * MAXPTS + i];
+            const double ddx = cx - (double)p.x;
+            const double ddy = cy - (double)p.y;
+            d2[i] = ddx * ddx + ddy * ddy;
+        }
+        __syncthreads();
+        const int lo = (m - 1) / 2, hi = m / 2;
+        for (int i = lane; i < m; i += 64) {
+            const double v = d2[i];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) {
+                const double u = d2[j];
+                rank += (u < v) || (u == v && j < i);
+            }
+            if (rank == lo) recs[slot].d2lo = v;
+            if (rank == hi) recs[slot].d2hi = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4 (host)
+// ---------------------------------------------------------------------------
+struct Center {
+    double x, y, radius;
+};
+
+// SimpleBlobDetector::detect()'s loop over thresholds, given that every
+// threshold sees the same centres `cur` (binary input).
+void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
+                     const hk_blob_params &p, std::vector<float> &out) {
+    std::vector<std::vector<Center>> groups;
+    const double min_dist = p.minDistBetweenBlobs;
+    for (int pass = 0; pass < n_thresholds; ++pass) {
+        const size_t existing = groups.size();
+        std::vector<std::vector<Center>> fresh;
+        for (const Center &c : cur) {
+            bool is_new = true;
+            for (size_t j = 0; j < existing; ++j) {
+                std::vector<Center> &g = groups[j];
+                const Center &mid = g[g.size() / 2];
+                const double ddx = mid.x - c.x, ddy = mid.y - c.y;
+                const double dist = std::sqrt(ddx * ddx + ddy * ddy);
+                is_new = dist >= min_dist && dist >= mid.radius &&
+                         dist >= c.radius;
+                if (!is_new) {
+                    // insert keeping the group sorted by radius
+                    size_t k = g.size();
+                    g.push_back(c);
+                    while (k > 0 && c.radius < g[k - 1].radius) {
+                        g[k] = g[k - 1];
+                        --k;
+                    }
+                    g[k] = c;
+                    break;
+                }
+            }
+            if (is_new) fresh.push_back(std::vector<Center>(1, c));
+        }
+        for (auto &g : fresh) groups.push_back(std::move(g));
+    }
+    for (const auto &g : groups) {
+        if ((int)g.size() < p.minRepeatability) continue;
+        double sx = 0, sy = 0, normalizer = 0;
+        for (const Center &c : g) {
+            sx += 1.0 * c.x;
+            sy += 1.0 * c.y;
+            normalizer += 1.0;
+        }
+        const double inv = 1. / normalizer;
+        sx *= inv;
+        sy *= inv;
+        out.push_back((float)sx);
+        out.push_back((float)sy);
+        out.push_back((float)(g[g.size() / 2].radius) * 2.0f);
+    }
+}
+
+}  // namespace
+
+struct hk_blob {
+    int width = 0, height = 0, max_frames = 0, device = 0;
+    hk_blob_params params;
+    DevParams dev;
+    int n_thresholds = 0;
+    unsigned cap_cand = 0, cap_blob = 0, eager = 0;
+    Cand *cands = nullptr;
+    unsigned *ctr = nullptr;
+    BlobRec *recs = nullptr;
+    ushort2 *pts = nullptr;
+    unsigned *h_ctr = nullptr;          // pinned
+    BlobRec *h_recs = nullptr;          // pinned, cap_blob entries
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr;
+    int pending_frames = 0;             // batch between enqueue and finish
+};
+
+extern "C" int hk_blob_params_hawkeye(hk_blob_params *p, int scan_height) {
+    if (!p) return hk::fail(HK_ERR_ARG, "hk_blob_params_hawkeye: null");
+    p->thresholdStep = 10;
+    p->minThreshold = 50;
+    p->maxThreshold = 220;
+    p->minRepeatability = 2;
+    p->minDistBetweenBlobs = 10;
+    p->filterByColor = 1;
+    p->blobColor = 255;
+    p->filterByArea = 1;
+    p->minArea = scan_height >= 480 ? 7.0f : 1.0f;
+    p->maxArea = scan_height >= 480 ? 1000.0f : 150.0f;
+    p->filterByCircularity = 1;
+    p->minCircularity = 0.3f;
+    p->maxCircularity = 1.1f;
+    p->filterByInertia = 0;
+    p->filterByConvexity = 0;
+    return HK_OK;
+}
+
+extern "C" int hk_blob_destroy(hk_blob *b) {
+    if (!b) return HK_OK;
+    hk::DeviceGuard guard(b->device);
+    (void)hipFree(b->cands);
+    (void)hipFree(b->ctr);
+    (void)hipFree(b->recs);
+    (void)hipFree(b->pts);
+    (void)hipHostFree(b->h_ctr);
+    (void)hipHostFree(b->h_recs);
+    if (b->done) (void)hipEventDestroy(b->done);
+    delete b;
+    return HK_OK;
+}
+
+extern "C" int hk_blob_create(int width, int height, int max_frames,
+                              const hk_blob_params *params, int device,
+                              hk_blob **out) {
+    if (!out || !params || width <= 0 || height <= 0 || max_frames <= 0)
+        return hk::fail(HK_ERR_ARG, "hk_blob_create: bad argument");
+    if (width > 65535 || height > 65535)
+        return hk::fail(HK_ERR_ARG, "hk_blob_create: frame larger than 65535");
+    if (params->filterByInertia || params->filterByConvexity)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_create: inertia/convexity filters are not "
+                        "supported (Hawkeye turns them off)");
+    if (!params->filterByArea || !params->filterByCircularity ||
+        !(params->minCircularity > 0.f) || !(params->maxArea > 0.f))
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_create: filterByArea and filterByCircularity "
+                        "(minCircularity > 0) are required: they bound the "
+                        "contour length the device trace follows");
+    if (params->filterByColor && params->blobColor != 255 &&
+        params->blobColor != 0)
+        return hk::fail(HK_ERR_ARG, "hk_blob_create: blobColor must be 0/255");
+    if (!(params->thresholdStep > 0.f) || params->minRepeatability <= 0)
+        return hk::fail(HK_ERR_ARG, "hk_blob_create: bad threshold settings");
+    // A contour that passes both filters has perimeter^2 <= 4 pi maxArea /
+    // minCircularity and at most `perimeter` points.
+    const double max_perim = std::sqrt(4 * 3.14159265358979323846 *
+                                       (double)params->maxArea /
+                                       (double)params->minCircularity);
+    const int max_pts = (int)std::floor(max_perim) + 3;
+    if (max_pts > MAXPTS)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_create: maxArea/minCircularity allow "
+                        "contours of %d points, more than the %d supported",
+                        max_pts, MAXPTS);
+    hk::DeviceGuard guard(device);
+    if (!guard.ok)
+        return hk::fail(HK_ERR_HIP, "hk_blob_create: cannot select device %d",
+                        device);
+    hk_blob *b = new hk_blob();
+    b->width = width;
+    b->height = height;
+    b->max_frames = max_frames;
+    b->device = device;
+    b->params = *params;
+    b->dev.filterByColor = params->filterByColor;
+    b->dev.blobColor = params->blobColor;
+    b->dev.minArea = params->minArea;
+    b->dev.maxArea = params->maxArea;
+    b->dev.minCirc = params->minCircularity;
+    b->dev.maxCirc = params->maxCircularity;
+    b->dev.max_pts = max_pts;
+    for (double t = params->minThreshold; t < params->maxThreshold;
+         t += params->thresholdStep)
+        ++b->n_thresholds;
+    b->cap_cand = (unsigned)max_frames * 8192u;
+    b->cap_blob = (unsigned)max_frames * 128u;
+    b->eager = std::min(b->cap_blob, (unsigned)max_frames * 48u);
+
+    hipError_t e = hipMalloc((void **)&b->cands, sizeof(Cand) * b->cap_cand);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->ctr, sizeof(unsigned) * CTR_WORDS);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->recs, sizeof(BlobRec) * b->cap_blob);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->pts,
+                      sizeof(ushort2) * MAXPTS * (size_t)b->cap_blob);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&b->h_ctr, sizeof(unsigned) * CTR_WORDS);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&b->h_recs, sizeof(BlobRec) * b->cap_blob);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        const char *msg = hipGetErrorString(e);
+        hk_blob_destroy(b);
+        return hk::fail(HK_ERR_ALLOC, "hk_blob_create: %s", msg);
+    }
+    *out = b;
+    return HK_OK;
+}
+
+extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
+                               long frame_stride, long pitch, int nframes,
+                               void *stream) {
+    if (!b || !mask_dev)
+        return hk::fail(HK_ERR_ARG, "hk_blob_enqueue: null argument");
+    if (nframes <= 0 || nframes > b->max_frames)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_enqueue: nframes %d outside 1..%d", nframes,
+                        b->max_frames);
+    if (pitch < b->width ||
+        (nframes > 1 && frame_stride < pitch * (long)b->height))
+        return hk::fail(HK_ERR_ARG, "hk_blob_enqueue: bad pitch/stride");
+    if (b->pending_frames)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_enqueue: previous batch not finished");
+    hk::DeviceGuard guard(b->device);
+    const hipStream_t s = (hipStream_t)stream;
+    const uint8_t *masks = (const uint8_t *)mask_dev;
+
+    HK_HIP(hipMemsetAsync(b->ctr, 0, sizeof(unsigned) * CTR_WORDS, s));
+    const int segs = (b->width + 15) / 16;
+    const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
+                     (nframes == 1 || frame_stride % 16 == 0);
+    const long total = (long)nframes * b->height * segs;
+    hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, s, masks, frame_stride, pitch, b->width,
+                       b->height, nframes, segs, vec, b->cands, b->ctr,
+                       b->cap_cand);
+    HK_LAUNCH_CHECK("blob_scan_k");
+    hipLaunchKernelGGL(blob_trace_k, dim3(2048), dim3(64), 0, s, masks,
+                       frame_stride, pitch, b->width, b->height, b->cands,
+                       b->ctr, b->cap_cand, b->recs, b->pts, b->cap_blob,
+                       b->dev);
+    HK_LAUNCH_CHECK("blob_trace_k");
+    hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
+                       b->cap_blob, b->recs, b->pts);
+    HK_LAUNCH_CHECK("blob_radius_k");
+    HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
+                          hipMemcpyDeviceToHost, s));
+    HK_HIP(hipMemcpyAsync(b->h_recs, b->recs, sizeof(BlobRec) * b->eager,
+                          hipMemcpyDeviceToHost, s));
+    HK_HIP(hipEventRecord(b->done, s));
+    b->stream = s;
+    b->pending_frames = nframes;
+    return HK_OK;
+}
+
+// Waits for the batch and returns the surviving contours per frame in the
+// order findContours(RETR_LIST) lists them (reverse discovery order).
+static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
+    if (!b) return hk::fail(HK_ERR_ARG, "hk_blob_finish: null handle");
+    if (!b->pending_frames)
+        return hk::fail(HK_ERR_ARG, "hk_blob_finish: nothing enqueued");
+    hk::DeviceGuard guard(b->device);
+    const int nframes = b->pending_frames;
+    b->pending_frames = 0;
+    HK_HIP(hipEventSynchronize(b->done));
+    const unsigned ncand = b->h_ctr[CTR_NCAND], nblob = b->h_ctr[CTR_NBLOB];
+    if (b->h_ctr[CTR_FLAGS] & FLAG_NONBINARY)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob: mask holds values other than 0 and 255");
+    if (ncand > b->cap_cand)
+        return hk::fail(HK_ERR_CAPACITY,
+                        "hk_blob: %u border candidates exceed capacity %u",
+                        ncand, b->cap_cand);
+    if (nblob > b->cap_blob)
+        return hk::fail(HK_ERR_CAPACITY,
+                        "hk_blob: %u contours exceed capacity %u", nblob,
+                        b->cap_blob);
+    if (nblob > b->eager) {
+        HK_HIP(hipMemcpyAsync(b->h_recs + b->eager, b->recs + b->eager,
+                              sizeof(BlobRec) * (nblob - b->eager),
+                              hipMemcpyDeviceToHost, b->stream));
+        HK_HIP(hipStreamSynchronize(b->stream));
+    }
+    std::vector<const BlobRec *> order(nblob);
+    for (unsigned i = 0; i < nblob; ++i) order[i] = &b->h_recs[i];
+    std::sort(order.begin(), order.end(),
+              [](const BlobRec *p, const BlobRec *q) {
+                  if (p->frame != q->frame) return p->frame < q->frame;
+                  return p->key > q->key;       // last discovered first
+              });
+    frames.assign(nframes, std::vector<Center>());
+    for (const BlobRec *r : order) {
+        if (r->frame < 0 || r->frame >= nframes)
+            return hk::fail(HK_ERR_INTERNAL, "hk_blob: bad frame index");
+        Center c;
+        c.x = r->cx;
+        c.y = r->cy;
+        c.radius = (std::sqrt(r->d2lo) + std::sqrt(r->d2hi)) / 2.;
+        frames[r->frame].push_back(c);
+    }
+    return HK_OK;
+}
+
+extern "C" int hk_blob_finish_centers(hk_blob *b, int *counts_host,
+                                      double *centers_host, int cap,
+                                      int *total) {
+    if (!counts_host || !centers_host || !total)
+        return hk::fail(HK_ERR_ARG, "hk_blob_finish_centers: null argument");
+    std::vector<std::vector<Center>> frames;
+    const int rc = collect(b, frames);
+    if (rc != HK_OK) return rc;
+    int n = 0;
+    for (size_t f = 0; f < frames.size(); ++f) {
+        counts_host[f] = (int)frames[f].size();
+        for (const Center &c : frames[f]) {
+            if (n < cap) {
+                centers_host[3 * n] = c.x;
+                centers_host[3 * n + 1] = c.y;
+                centers_host[3 * n + 2] = c.radius;
+            }
+            ++n;
+        }
+    }
+    *total = n;
+    if (n > cap)
+        return hk::fail(HK_ERR_CAPACITY, "hk_blob: %d centres, capacity %d",
+                        n, cap);
+    return HK_OK;
+}
+
+extern "C" int hk_blob_finish(hk_blob *b, int *counts_host, float *kp_host,
+                              int cap, int *total) {
+    if (!counts_host || !kp_host || !total)
+        return hk::fail(HK_ERR_ARG, "hk_blob_finish: null argument");
+    std::vector<std::vector<Center>> frames;
+    const int rc = collect(b, frames);
+    if (rc != HK_OK) return rc;
+    int n = 0;
+    std::vector<float> kp;
+    for (size_t f = 0; f < frames.size(); ++f) {
+        kp.clear();
+        group_keypoints(frames[f], b->n_thresholds, b->params, kp);
+        const int k = (int)(kp.size() / 3);
+        counts_host[f] = k;
+        for (int i = 0; i < k; ++i, ++n)
+            if (n < cap) std::memcpy(kp_host + 3 * (size_t)n, &kp[3 * i],
+                                     3 * sizeof(float));
+    }
+    *total = n;
+    if (n > cap)
+        return hk::fail(HK_ERR_CAPACITY, "hk_blob: %d keypoints, capacity %d",
+                        n, cap);
+    return HK_OK;
+}
+
+extern "C" int hk_blob_detect(hk_blob *b, const void *mask_dev,
+                              long frame_stride, long pitch, int nframes,
+                              void *stream, int *counts_host, float *kp_host,
+                              int cap, int *total) {
+    const int rc = hk_blob_enqueue(b, mask_dev, frame_stride, pitch, nframes,
+                                   stream);
+    if (rc != HK_OK) return rc;
+    return hk_blob_finish(b, counts_host, kp_host, cap, total);
+}

@@ -32,9 +32,9 @@ class BackgroundSubtractorMOG:
         self._h = h
 
     def close(self):
-        if getattr(self, '_h', None):
-            nat.lib.hk_mog_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, '_h', None), None
+        if h and nat is not None and getattr(nat, 'lib', None) is not None:
+            nat.lib.hk_mog_destroy(h)
 
     __del__ = close
 
@@ -93,4 +93,103 @@ class BackgroundSubtractorMOG:
         out = np.empty((self.height * self.width, 5, 8), np.float32)
         nat.check(nat.lib.hk_mog_export_model(self._h, out.ctypes.data,
                                               _stream_ptr(self.device)))
+        return out
+
+
+def hawkeye_blob_params(scan_height):
+    """The SimpleBlobDetector parameter block the reference builds
+    (reference tracker.py:359-374)."""
+    p = nat.BlobParams()
+    nat.check(nat.lib.hk_blob_params_hawkeye(nat.C.byref(p), int(scan_height)))
+    return p
+
+
+class SimpleBlobDetector:
+    """``cv2.SimpleBlobDetector_create(params)`` for binary device masks.
+
+    ``detect(masks)`` takes uint8 masks [T][H][W] (or one [H][W]) on the
+    device and returns, per frame, a float32 array [n][3] of keypoints
+    (x, y, size) in OpenCV's order.
+    """
+
+    def __init__(self, width, height, params=None, max_frames=64, device=0):
+        self.width, self.height = int(width), int(height)
+        self.max_frames = int(max_frames)
+        self.device = torch.device('cuda', device)
+        self.params = params if params is not None else \
+            hawkeye_blob_params(height)
+        h = nat.C.c_void_p()
+        nat.check(nat.lib.hk_blob_create(self.width, self.height,
+                                         self.max_frames,
+                                         nat.C.byref(self.params), device,
+                                         nat.C.byref(h)))
+        self._h = h
+        self._cap = self.max_frames * 128
+        self._counts = np.empty(self.max_frames, np.int32)
+        self._kp = np.empty((self._cap, 3), np.float32)
+        self._centers = np.empty((self._cap, 3), np.float64)
+        self._pending = 0
+
+    def close(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h and nat is not None and getattr(nat, 'lib', None) is not None:
+            nat.lib.hk_blob_destroy(h)
+
+    __del__ = close
+
+    def _check_masks(self, masks):
+        if masks.dim() == 2:
+            masks = masks.unsqueeze(0)
+        if (masks.dtype != torch.uint8 or masks.device != self.device or
+                masks.dim() != 3 or
+                tuple(masks.shape[1:]) != (self.height, self.width)):
+            raise ValueError('masks must be uint8 [T][{}][{}] on {}'.format(
+                self.height, self.width, self.device))
+        if masks.stride(2) != 1:
+            masks = masks.contiguous()
+        return masks
+
+    def enqueue(self, masks):
+        """Start detection on up to max_frames masks; returns immediately.
+        The caller must keep `masks` alive until finish()."""
+        masks = self._check_masks(masks)
+        nat.check(nat.lib.hk_blob_enqueue(
+            self._h, masks.data_ptr(), masks.stride(0), masks.stride(1),
+            masks.shape[0], _stream_ptr(self.device)))
+        self._pending = masks.shape[0]
+        self._keep = masks
+
+    def _split(self, flat, total):
+        out, k = [], 0
+        for t in range(self._pending):
+            n = int(self._counts[t])
+            out.append(flat[k:k + n].copy())
+            k += n
+        assert k == total
+        self._pending = 0
+        self._keep = None
+        return out
+
+    def finish(self):
+        total = nat.C.c_int()
+        nat.check(nat.lib.hk_blob_finish(
+            self._h, self._counts.ctypes.data, self._kp.ctypes.data,
+            self._cap, nat.C.byref(total)))
+        return self._split(self._kp, total.value)
+
+    def finish_centers(self):
+        """Per-contour stage only: float64 [n][3] (x, y, radius) per frame,
+        what one findBlobs() pass yields.  For tests."""
+        total = nat.C.c_int()
+        nat.check(nat.lib.hk_blob_finish_centers(
+            self._h, self._counts.ctypes.data, self._centers.ctypes.data,
+            self._cap, nat.C.byref(total)))
+        return self._split(self._centers, total.value)
+
+    def detect(self, masks):
+        masks = self._check_masks(masks)
+        out = []
+        for s in range(0, masks.shape[0], self.max_frames):
+            self.enqueue(masks[s:s + self.max_frames])
+            out.extend(self.finish())
         return out

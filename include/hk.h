@@ -83,6 +83,67 @@ int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
  * (sortKey, weight, mean[3], var[3]).  For tests.  Synchronises. */
 int hk_mog_export_model(hk_mog *m, float *host_out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * K2-K4  blob detection on binary masks
+ *     replaces cv2.SimpleBlobDetector_create(params).detect(fgmask)
+ *     (reference tracker.py:359-374, 396): findContours(RETR_LIST,
+ *     CHAIN_APPROX_NONE) + contour moments / arcLength / colour test / median
+ *     radius per contour, then the cross-threshold grouping loop, returning
+ *     float32 keypoints (x, y, size) in OpenCV's order.
+ *
+ *     Supported parameter space = what Hawkeye uses: filterByArea and
+ *     filterByCircularity on (they bound the contour length, which bounds the
+ *     device trace), filterByInertia and filterByConvexity off.  The input
+ *     must be a binary mask (every byte 0 or 255, as MOG writes it); then all
+ *     binarisation thresholds see the same image.  Anything else is rejected
+ *     with HK_ERR_ARG.
+ * ---------------------------------------------------------------------- */
+typedef struct hk_blob_params {
+    float thresholdStep, minThreshold, maxThreshold;
+    int minRepeatability;
+    float minDistBetweenBlobs;
+    int filterByColor;
+    int blobColor;
+    int filterByArea;
+    float minArea, maxArea;
+    int filterByCircularity;
+    float minCircularity, maxCircularity;
+    int filterByInertia;
+    int filterByConvexity;
+} hk_blob_params;
+
+/* The block reference tracker.py:359-374 builds for a scan video of the given
+ * height (OpenCV defaults + Hawkeye's overrides). */
+int hk_blob_params_hawkeye(hk_blob_params *p, int scan_height);
+
+typedef struct hk_blob hk_blob;
+
+/* Work buffers for batches of up to max_frames masks of width x height. */
+int hk_blob_create(int width, int height, int max_frames,
+                   const hk_blob_params *params, int device, hk_blob **out);
+int hk_blob_destroy(hk_blob *b);
+
+/* Enqueue detection on `nframes` masks (mask t at mask_dev + t*frame_stride,
+ * rows `pitch` bytes apart) on `stream`.  Returns immediately. */
+int hk_blob_enqueue(hk_blob *b, const void *mask_dev, long frame_stride,
+                    long pitch, int nframes, void *stream);
+/* Wait for the enqueued batch and finish on the host (ordering, radius,
+ * grouping).  counts_host[t] = keypoints of frame t; kp_host receives
+ * (x, y, size) float triples, frame after frame; *total = sum of counts.
+ * HK_ERR_CAPACITY if total > cap (nothing beyond cap is written). */
+int hk_blob_finish(hk_blob *b, int *counts_host, float *kp_host, int cap,
+                   int *total);
+/* hk_blob_enqueue + hk_blob_finish. */
+int hk_blob_detect(hk_blob *b, const void *mask_dev, long frame_stride,
+                   long pitch, int nframes, void *stream, int *counts_host,
+                   float *kp_host, int cap, int *total);
+
+/* Per-contour stage only (one findBlobs() pass), for tests: centres that
+ * survive the filters as double (x, y, radius) triples, per frame in OpenCV's
+ * contour order.  Same calling convention as hk_blob_finish. */
+int hk_blob_finish_centers(hk_blob *b, int *counts_host, double *centers_host,
+                           int cap, int *total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""
+GPU parity: the HIP blob detector (through the C ABI) against the C oracle's
+restatement of cv2.SimpleBlobDetector, bit for bit, on the same masks:
+per-contour centres (float64 x, y, radius) and final keypoints (float32).
+"""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def mask_shapes(rng, h, w, n_discs=14, specks=30, big=True):
+    """Discs/ellipses of many sizes, rings, touching pairs, edge blobs, a
+    large 'juggler' region and single-pixel specks."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = np.zeros((h, w), bool)
+    for _ in range(n_discs):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        a, b = rng.uniform(1.0, 14.0), rng.uniform(1.0, 14.0)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        e = (u / a)**2 + (v / b)**2 <= 1
+        if rng.uniform() < 0.3:
+            e &= ~((u / (a * 0.5))**2 + (v / (b * 0.5))**2 <= 1)    # ring
+        m |= e
+    if big:
+        m[h // 3:h // 3 + h // 2, w // 2:w // 2 + w // 5] = True
+        m[h // 3 + 5:h // 3 + 9, w // 2 + 3:w // 2 + 9] = False     # hole
+    for _ in range(specks):
+        m[rng.randint(0, h), rng.randint(0, w)] ^= True
+    return m.astype(np.uint8) * 255
+
+
+def mask_smooth_noise(rng, h, w, size, thr):
+    f = ndimage.uniform_filter(rng.uniform(size=(h, w)), size)
+    return (f > thr).astype(np.uint8) * 255
+
+
+def oracle_results(masks, params_height):
+    from oracle import detect_ref as D
+    p = D.hawkeye_params(params_height)
+    return ([D.find_blobs(m, p) for m in masks],
+            [D.blob_detect(m, p) for m in masks])
+
+
+def check_against_oracle(masks, params_height=None):
+    from hawkeye_amd.detect import SimpleBlobDetector, hawkeye_blob_params
+    t, h, w = masks.shape
+    ph = h if params_height is None else params_height
+    want_c, want_k = oracle_results(masks, ph)
+    det = SimpleBlobDetector(w, h, params=hawkeye_blob_params(ph),
+                             max_frames=max(1, min(t, 16)))
+    dev = torch.from_numpy(masks).cuda()
+    got_c = []
+    for s in range(0, t, det.max_frames):
+        det.enqueue(dev[s:s + det.max_frames])
+        got_c.extend(det.finish_centers())
+    got_k = det.detect(dev)
+    n_c = n_k = 0
+    for f in range(t):
+        assert got_c[f].shape == want_c[f].shape, \
+            'frame {}: {} centres, oracle {}'.format(f, len(got_c[f]),
+                                                     len(want_c[f]))
+        assert np.array_equal(got_c[f].view(np.uint64),
+                              want_c[f].view(np.uint64)), 'frame {}'.format(f)
+        assert got_k[f].shape == want_k[f].shape
+        assert np.array_equal(got_k[f].view(np.uint32),
+                              want_k[f].view(np.uint32)), 'frame {}'.format(f)
+        n_c += len(want_c[f])
+        n_k += len(want_k[f])
+    return n_c, n_k
+
+
+@pytest.mark.parametrize('h,w', [(96, 128), (61, 83), (480, 640)])
+def test_shapes_match_oracle(h, w):
+    rng = np.random.RandomState(h + w)
+    masks = np.stack([mask_shapes(rng, h, w) for _ in range(12)])
+    n_c, n_k = check_against_oracle(masks)
+    assert n_c > 20 and n_k > 10
+
+
+def test_low_res_parameter_block():
+    rng = np.random.RandomState(4)
+    masks = np.stack([mask_shapes(rng, 120, 160, n_discs=10) for _ in
+                      range(6)])
+    n_c, n_k = check_against_oracle(masks, params_height=360)
+    assert n_c > 10
+
+
+@pytest.mark.parametrize('size,thr', [(3, 0.5), (5, 0.5), (7, 0.52),
+                                      (3, 0.62), (9, 0.5), (4, 0.4)])
+def test_messy_topology_matches_oracle(size, thr):
+    """Thresholded smoothed noise: nested holes, islands in holes, diagonal
+    links, one-pixel bridges -- everything border following can meet."""
+    rng = np.random.RandomState(size * 100 + int(thr * 100))
+    masks = np.stack([mask_smooth_noise(rng, 90, 117, size, thr)
+                      for _ in range(8)])
+    check_against_oracle(masks)
+    check_against_oracle(masks, params_height=300)
+
+
+def test_pure_noise_and_extremes():
+    rng = np.random.RandomState(17)
+    masks = np.stack(
+        [(rng.uniform(size=(64, 80)) < d).astype(np.uint8) * 255
+         for d in (0.02, 0.1, 0.3, 0.5, 0.7, 0.9)] +
+        [np.zeros((64, 80), np.uint8), np.full((64, 80), 255, np.uint8)])
+    check_against_oracle(masks)
+    check_against_oracle(masks, params_height=300)
+
+
+def test_full_hd_sparse_blobs():
+    rng = np.random.RandomState(23)
+    h, w = 1080, 1920
+    masks = np.stack([mask_shapes(rng, h, w, n_discs=40, specks=200)
+                      for _ in range(3)])
+    n_c, n_k = check_against_oracle(masks)
+    assert n_k >= 20
+
+
+def test_rejects_non_binary_mask_and_bad_params():
+    from hawkeye_amd import _native as nat
+    from hawkeye_amd.detect import SimpleBlobDetector, hawkeye_blob_params
+    det = SimpleBlobDetector(64, 48)
+    m = torch.zeros((1, 48, 64), dtype=torch.uint8, device='cuda')
+    m[0, 10:20, 10:20] = 255
+    assert len(det.detect(m)[0]) == 1
+    m[0, 30, 30] = 128
+    with pytest.raises(nat.NativeError, match='other than 0 and 255'):
+        det.detect(m)
+    p = hawkeye_blob_params(720)
+    p.filterByInertia = 1
+    with pytest.raises(nat.NativeError, match='inertia'):
+        SimpleBlobDetector(64, 48, params=p)
+    p = hawkeye_blob_params(720)
+    p.maxArea = 50000.0
+    with pytest.raises(nat.NativeError, match='points'):
+        SimpleBlobDetector(64, 48, params=p)
