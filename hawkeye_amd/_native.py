@@ -92,6 +92,56 @@ _sig('hk_blob_detect', [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int,
 _sig('hk_blob_finish_centers', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(C.c_int)])
 
+_sig('hk_render_frames', [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_float,
+                          C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int,
+                          C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long,
+                          C.c_void_p])
+
+
+class ScanParams(C.Structure):
+    """hk_scan_params (include/hk.h): the scanner constants of reference
+    tracker.py:2510-2570 that steps 3-4 read, plus the keys step 2 derives."""
+    _fields_ = [('sigmasq', C.c_double), ('max_frame_gap_in_arc', C.c_int),
+                ('g_window', C.c_double), ('min_tags_to_curve_fit', C.c_int),
+                ('default_frame_height_cm', C.c_double),
+                ('max_frame_height_cm', C.c_double),
+                ('default_fps', C.c_double), ('max_fps', C.c_double),
+                ('min_tags_per_arc', C.c_int),
+                ('max_distance_pixels', C.c_double),
+                ('radius_window', C.c_double)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+_sig('hk_scan_params_default', [C.POINTER(ScanParams), C.c_int, C.c_int,
+                                C.c_double])
+_sig('hk_clip_create', [C.c_int, C.c_int, C.c_double, C.c_int,
+                        C.POINTER(ScanParams), C.c_int, C.c_void_p,
+                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                        C.c_int, c_void_pp])
+_sig('hk_clip_destroy', [C.c_void_p])
+_sig('hk_clip_set_progress', [C.c_void_p, PROGRESS_FN, C.c_void_p])
+_sig('hk_clip_set_state', [C.c_void_p, C.c_double, C.c_int, C.c_double])
+_sig('hk_clip_get_state', [C.c_void_p, C.POINTER(C.c_double),
+                           C.POINTER(C.c_int), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double)])
+_sig('hk_clip_set_arcs', [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_void_p])
+_sig('hk_clip_arc_count', [C.c_void_p])
+_sig('hk_clip_arc_tag_total', [C.c_void_p])
+_sig('hk_clip_get_arcs', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_void_p])
+_sig('hk_clip_get_tag_state', [C.c_void_p, C.c_void_p, C.c_void_p])
+_sig('hk_clip_build_initial_arcs', [C.c_void_p])
+_sig('hk_clip_em_optimize', [C.c_void_p, C.c_void_p])
+_sig('hk_clip_calculate_weights', [C.c_void_p, C.c_void_p])
+_sig('hk_clip_fit_arcs', [C.c_void_p, C.c_void_p])
+_sig('hk_clip_estimate_camera_tilt', [C.c_void_p, C.c_void_p])
+_sig('hk_clip_get_weights', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_int, C.c_void_p])
+_sig('hk_clip_eval_arc', [C.c_void_p, C.c_int, C.c_int, C.c_int])
+_sig('hk_clip_member_distances', [C.c_void_p, C.c_void_p, C.c_void_p])
+
 
 def check(status):
     """Raise NativeError for a negative status, else return the status."""

@@ -1,0 +1,913 @@
+// Steps 3-4 host logic: preliminary arc construction (reference
+// tracker.py:450-696, 880-906) and the merge / prune / clean control flow of
+// EM_optimize (reference tracker.py:912-990, 1126-1435).  The batched
+// arithmetic of step 4 -- E-step, M-step, tilt, member distances -- runs on
+// the GPU (hk_em.hip); what stays here is the order-dependent, sequential
+// part plus the single-arc trial fits of construct_arcs / merge_arcs.
+//
+// Tags are indices into SoA arrays ordered by (frame, position in the frame's
+// list).  Where the reference iterates Python sets (address order, not
+// reproducible) this code iterates in ascending tag index and breaks exact
+// ties towards the lower index, like oracle/em_ref.py.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "hk_clip.h"
+
+namespace hk {
+
+namespace {
+
+constexpr double G_CM = 980.7;
+
+// Python's int(v) for a float that may be far outside int range; results are
+// clamped to [0, F) by the callers, so saturating at +-1e9 changes nothing.
+long trunc_to_int(double v) {
+    if (!(v > -1e9)) return -1000000000L;
+    if (!(v < 1e9)) return 1000000000L;
+    return (long)v;
+}
+
+struct Moments {
+    double T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+    double X1 = 0, TX = 0, T2X = 0, Y1 = 0, TY = 0, T2Y = 0;
+};
+
+template <class WeightOf>
+Moments moments(const hk_clip &c, const Arc &arc, const std::vector<int> &tags,
+                WeightOf weight_of) {
+    Moments m;
+    for (int i : tags) {
+        const double t = c.frame[i] - arc.f_peak;
+        const double w = weight_of(i);
+        const double x = c.x[i], y = c.y[i];
+        const double t2 = t * t;
+        m.T0 += w;
+        m.T1 += w * t;
+        m.T2 += w * t2;
+        m.T3 += w * (t2 * t);
+        m.T4 += w * (t2 * t2);
+        m.X1 += w * x;
+        m.TX += w * t * x;
+        m.T2X += w * t2 * x;
+        m.Y1 += w * y;
+        m.TY += w * t * y;
+        m.T2Y += w * t2 * y;
+    }
+    return m;
+}
+
+}  // namespace
+
+Rot rotation(const hk_clip &clip) {
+    return Rot{std::sin(clip.tilt), std::cos(clip.tilt)};
+}
+
+void arc_position(const Arc &arc, double frame, const Rot &rot, double &px,
+                  double &py) {
+    const double t = frame - arc.f_peak;
+    const double xj = arc.a + arc.b * t;
+    const double yj = arc.c + arc.e * t * t;
+    px = xj * rot.c + yj * rot.s;
+    py = yj * rot.c - xj * rot.s;
+}
+
+double arc_tag_distance(const hk_clip &clip, const Arc &arc, const Rot &rot,
+                        int tag) {
+    double px, py;
+    arc_position(arc, (double)clip.frame[tag], rot, px, py);
+    const double dx = px - clip.x[tag], dy = py - clip.y[tag];
+    return std::sqrt(dx * dx + dy * dy);
+}
+
+// reference types.py:79-102, quirks included (juggler-coordinate a, b, c
+// against screen width/height; int(v + 1) on both ends).
+void arc_frame_range(const hk_clip &clip, const Arc &arc, int &f_min,
+                     int &f_max) {
+    const double F = clip.F;
+    double lo_x, hi_x;
+    if (arc.b == 0) {
+        lo_x = 0;
+        hi_x = F;
+    } else {
+        lo_x = arc.f_peak - arc.a / arc.b;
+        hi_x = arc.f_peak + (clip.W - arc.a) / arc.b;
+    }
+    if (lo_x > hi_x) std::swap(lo_x, hi_x);
+    const long ilo_x = trunc_to_int(lo_x + 1), ihi_x = trunc_to_int(hi_x + 1);
+
+    const double q = (clip.H - arc.c) / arc.e;
+    double lo_y = q < 0 ? 0.0 : arc.f_peak - std::sqrt(q);
+    double hi_y = arc.e < 0 ? F : 2 * arc.f_peak - lo_y;
+    if (lo_y > hi_y) std::swap(lo_y, hi_y);
+    const long ilo_y = trunc_to_int(lo_y + 1), ihi_y = trunc_to_int(hi_y + 1);
+
+    f_min = (int)std::max(0L, std::max(ilo_x, ilo_y));
+    f_max = (int)std::min((long)clip.F - 1, std::min(ihi_x, ihi_y));
+}
+
+double median_tag_radius(const hk_clip &clip, const std::vector<int> &tags) {
+    std::vector<double> v;
+    v.reserve(tags.size());
+    for (int i : tags) v.push_back(clip.r[i]);
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    if (n % 2 == 1) return v[n / 2];
+    return (v[n / 2 - 1] + v[n / 2]) / 2;
+}
+
+bool acceleration_ok(const hk_clip &clip, double e) {
+    if (e < 0) return false;
+    if (clip.has_g) {
+        const double gw = clip.p.g_window;
+        if (2 * e < (1 - gw) * clip.g) return false;
+        if (2 * e > (1 + gw) * clip.g) return false;
+        return true;
+    }
+    const double max_cm_per_px = clip.p.max_frame_height_cm / clip.H;
+    if (2 * e < G_CM / (max_cm_per_px * (clip.fps * clip.fps))) return false;
+    return true;
+}
+
+namespace {
+
+// Weighted parabola fit of one arc over `tags` (reference tracker.py:713-798).
+// Leaves the arc untouched if the normal equations are near singular.
+template <class WeightOf>
+void fit_one(const hk_clip &c, Arc &arc, const std::vector<int> &tags,
+             const Rot &rot, WeightOf weight_of) {
+    if (tags.size() < 3) return;
+    const Moments m = moments(c, arc, tags, weight_of);
+    const double T0 = m.T0, T1 = m.T1, T2 = m.T2, T3 = m.T3, T4 = m.T4;
+    const double det2 = T0 * T2 - T1 * T1;
+    const double det3 = 2 * T1 * T2 * T3 + T0 * T2 * T4 - T0 * (T3 * T3) -
+                        (T1 * T1) * T4 - T2 * T2 * T2;
+    if (std::fabs(det2) < 1e-3 || std::fabs(det3) < 1e-3) return;
+    const double s = rot.s, cs = rot.c;
+    const double bx1 = cs * m.TX - s * m.TY;
+    const double bx2 = cs * m.X1 - s * m.Y1;
+    const double b_new = (T0 * bx1 - T1 * bx2) / det2;
+    double a_new = (-T1 * bx1 + T2 * bx2) / det2;
+    const double m11 = T0 * T2 - T1 * T1;
+    const double m12 = T1 * T2 - T0 * T3;
+    const double m13 = T1 * T3 - T2 * T2;
+    const double m22 = T0 * T4 - T2 * T2;
+    const double m23 = T2 * T3 - T1 * T4;
+    const double m33 = T2 * T4 - T3 * T3;
+    const double by1 = cs * m.T2Y + s * m.T2X;
+    const double by2 = cs * m.TY + s * m.TX;
+    const double by3 = cs * m.Y1 + s * m.X1;
+    const double e_new = (m11 * by1 + m12 * by2 + m13 * by3) / det3;
+    const double d_new = (m12 * by1 + m22 * by2 + m23 * by3) / det3;
+    double c_new = (m13 * by1 + m23 * by2 + m33 * by3) / det3;
+    if (std::isnan(a_new) || std::isnan(b_new) || std::isnan(c_new) ||
+        std::isnan(d_new) || std::isnan(e_new) || e_new == 0)
+        return;
+    const double shift = -d_new / (2.0 * e_new);
+    arc.f_peak += shift;
+    a_new += b_new * shift;
+    c_new += d_new * shift + e_new * (shift * shift);
+    arc.a = a_new;
+    arc.b = b_new;
+    arc.c = c_new;
+    arc.e = e_new;
+}
+
+// eval_arc with distances computed here (reference tracker.py:800-840).
+int eval_arc_host(const hk_clip &c, const Arc &arc, const Rot &rot,
+                  bool requirepeak, bool checkaccel) {
+    if (std::isnan(arc.a) || std::isnan(arc.b) || std::isnan(arc.c) ||
+        std::isnan(arc.e) || std::isnan(arc.f_peak))
+        return 1;
+    if (arc.tags.empty()) return 5;
+    if (requirepeak) {
+        int lo = c.frame[arc.tags[0]], hi = lo;
+        for (int i : arc.tags) {
+            lo = std::min(lo, c.frame[i]);
+            hi = std::max(hi, c.frame[i]);
+        }
+        if (!(lo <= arc.f_peak && arc.f_peak <= hi)) return 3;
+    }
+    if (checkaccel && !acceleration_ok(c, arc.e)) return 4;
+    int close = 0;
+    for (int i : arc.tags)
+        if (arc_tag_distance(c, arc, rot, i) < c.p.max_distance_pixels) ++close;
+    return close < c.p.min_tags_per_arc ? 2 : 0;
+}
+
+int report_progress(hk_clip &c) {
+    if (c.progress && c.progress(c.progress_user) != 0)
+        return fail(HK_ERR_ABORTED, "aborted by the progress callback");
+    return HK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// step 3
+// ---------------------------------------------------------------------------
+
+class ArcBuilder {
+public:
+    explicit ArcBuilder(hk_clip &c)
+        : c_(c), nb_(c.n), nb_ready_(c.n, 0), in_frontier_(c.n, 0),
+          taken_(c.F > 0 ? c.F : 1, 0) {
+        has_vmax_ = c.has_g;
+        if (has_vmax_) v_max_ = std::sqrt(2 * c.g * c.H);
+    }
+
+    // Neighbours of tag i: every tag within max_frame_gap_in_arc + 1 frames,
+    // other frames only, ordered by the speed needed to get there (stable),
+    // capped at v_max once g is known (reference tracker.py:654-696).  Built
+    // on first use; the reference builds all of them up front, which yields
+    // the same lists.
+    const std::vector<int> &neighbors(int i) {
+        if (nb_ready_[i]) return nb_[i];
+        const int f = c_.frame[i];
+        const int gap = c_.p.max_frame_gap_in_arc;
+        const int lo = std::max(0, f - gap - 1);
+        const int hi = std::min(c_.F, f + gap + 2);
+        cand_.clear();
+        vel_.clear();
+        for (int j = c_.start[lo]; j < c_.start[hi]; ++j) {
+            if (c_.frame[j] == f) continue;
+            const double dx = c_.x[j] - c_.x[i], dy = c_.y[j] - c_.y[i];
+            cand_.push_back(j);
+            vel_.push_back(std::sqrt(dx * dx + dy * dy) /
+                           std::abs(c_.frame[j] - f));
+        }
+        order_.resize(cand_.size());
+        std::iota(order_.begin(), order_.end(), 0);
+        std::stable_sort(order_.begin(), order_.end(),
+                         [&](int p, int q) { return vel_[p] < vel_[q]; });
+        std::vector<int> &out = nb_[i];
+        out.reserve(order_.size());
+        for (int k : order_)
+            if (!has_vmax_ || vel_[k] <= v_max_) out.push_back(cand_[k]);
+        nb_ready_[i] = 1;
+        return out;
+    }
+
+    int construct(int maxcount, std::vector<Arc> &out) {
+        hk_clip &c = c_;
+        const double maxd = c.p.max_distance_pixels;
+        const Rot rot = rotation(c);
+        std::vector<int> queue(c.n);
+        std::iota(queue.begin(), queue.end(), 0);
+        std::stable_sort(queue.begin(), queue.end(),
+                         [&](int p, int q) { return c.y[p] < c.y[q]; });
+        std::vector<char> done(c.n, 0);
+        double e0;
+        if (c.has_g) {
+            e0 = 0.5 * c.g;
+        } else {
+            const double cm_per_px = c.p.default_frame_height_cm / c.H;
+            e0 = 0.5 * G_CM / (cm_per_px * (c.fps * c.fps));
+        }
+        auto unit = [](int) { return 1.0; };
+        std::vector<int> members, frontier;
+        int since_progress = 0;
+
+        for (int t1 : queue) {
+            if (done[t1]) continue;
+            bool made = false;
+            // nb_ has one slot per tag from the start, so this reference
+            // stays valid while other tags' lists are built
+            const std::vector<int> &nb1 = neighbors(t1);
+            for (int t2 : nb1) {
+                if (done[t2]) continue;
+                ++stamp_;
+                Arc arc;
+                const int f1 = c.frame[t1], f2 = c.frame[t2];
+                members.clear();
+                members.push_back(std::min(t1, t2));
+                members.push_back(std::max(t1, t2));
+                taken_[f1] = stamp_;
+                taken_[f2] = stamp_;
+                frontier.clear();
+                add_to_frontier(nb1, done, frontier);
+                add_to_frontier(neighbors(t2), done, frontier);
+
+                arc.e = e0;
+                arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
+                             0.5 * (f1 + f2);
+                const double dt1 = f1 - arc.f_peak;
+                arc.c = c.y[t1] - arc.e * (dt1 * dt1);
+                arc.b = (c.x[t1] - c.x[t2]) / (f1 - f2);
+                arc.a = c.x[t1] - arc.b * (f1 - arc.f_peak);
+
+                bool bad = false;
+                while (!frontier.empty()) {
+                    int best = -1;
+                    double best_d = 0;
+                    for (int j : frontier) {
+                        const double d = arc_tag_distance(c, arc, rot, j);
+                        if (best < 0 || d < best_d ||
+                            (d == best_d && j < best)) {
+                            best = j;
+                            best_d = d;
+                        }
+                    }
+                    if (best_d > maxd) break;
+                    members.insert(std::upper_bound(members.begin(),
+                                                    members.end(), best),
+                                   best);
+                    taken_[c.frame[best]] = stamp_;
+                    add_to_frontier(neighbors(best), done, frontier);
+                    frontier.erase(
+                        std::remove_if(frontier.begin(), frontier.end(),
+                                       [&](int j) {
+                                           return taken_[c.frame[j]] == stamp_;
+                                       }),
+                        frontier.end());
+                    if ((int)members.size() > c.p.min_tags_to_curve_fit)
+                        fit_one(c, arc, members, rot, unit);
+                    if (std::isnan(arc.e) || arc.e <= 0) {
+                        bad = true;
+                        break;
+                    }
+                    for (int j : members)
+                        if (arc_tag_distance(c, arc, rot, j) > maxd) {
+                            bad = true;
+                            break;
+                        }
+                    if (bad) break;
+                }
+                if (!bad) {
+                    arc.tags = members;
+                    if (eval_arc_host(c, arc, rot, false, true) == 0) {
+                        for (int j : members) done[j] = 1;
+                        out.push_back(arc);
+                        made = true;
+                    }
+                }
+                if (made) break;
+            }
+            if (maxcount > 0 && (int)out.size() >= maxcount) break;
+            if (++since_progress >= 256) {
+                since_progress = 0;
+                const int rc = report_progress(c);
+                if (rc != HK_OK) return rc;
+            }
+            done[t1] = 1;
+        }
+        return HK_OK;
+    }
+
+private:
+    void add_to_frontier(const std::vector<int> &src,
+                         const std::vector<char> &done,
+                         std::vector<int> &frontier) {
+        for (int j : src) {
+            if (done[j] || taken_[c_.frame[j]] == stamp_ ||
+                in_frontier_[j] == stamp_)
+                continue;
+            in_frontier_[j] = stamp_;
+            frontier.push_back(j);
+        }
+    }
+
+    hk_clip &c_;
+    std::vector<std::vector<int>> nb_;
+    std::vector<char> nb_ready_;
+    std::vector<int> in_frontier_, taken_;
+    int stamp_ = 0;
+    bool has_vmax_ = false;
+    double v_max_ = 0;
+    std::vector<int> cand_, order_;
+    std::vector<double> vel_;
+};
+
+void find_global_params(hk_clip &c, const std::vector<Arc> &arcs) {
+    if (arcs.empty()) return;
+    std::vector<const Arc *> top;
+    top.reserve(arcs.size());
+    for (const Arc &a : arcs) top.push_back(&a);
+    std::stable_sort(top.begin(), top.end(), [](const Arc *p, const Arc *q) {
+        return p->tags.size() > q->tags.size();
+    });
+    if (top.size() > 10) top.resize(10);
+    std::vector<double> es;
+    for (const Arc *a : top) es.push_back(a->e);
+    std::sort(es.begin(), es.end());
+    const size_t n = es.size();
+    const double med = (n % 2) ? es[n / 2] : (es[n / 2 - 1] + es[n / 2]) / 2;
+    c.g = 2 * med;
+    c.has_g = true;
+    c.cm_per_pixel = G_CM / (c.g * (c.fps * c.fps));
+}
+
+// ---------------------------------------------------------------------------
+// step 4 host parts
+// ---------------------------------------------------------------------------
+
+struct MergeCache {         // per arc, valid while the arc is unchanged
+    bool valid = false;
+    int f_min = 0, f_max = 0;
+    std::vector<int> good;
+};
+
+void refresh_cache(const hk_clip &c, const Arc &arc, const Rot &rot,
+                   const double *dist, MergeCache &mc) {
+    // dist: member distances (arc.tags order) from K7, or null -> host
+    mc.valid = true;
+    mc.good.clear();
+    if (arc.tags.empty()) return;
+    arc_frame_range(c, arc, mc.f_min, mc.f_max);
+    const double m = median_tag_radius(c, arc.tags);
+    const double r_lo = m * (1 - c.p.radius_window);
+    const double r_hi = m * (1 + c.p.radius_window);
+    for (size_t k = 0; k < arc.tags.size(); ++k) {
+        const int i = arc.tags[k];
+        const double d = dist ? dist[k] : arc_tag_distance(c, arc, rot, i);
+        if (d < c.p.max_distance_pixels && c.tw[i] > 0.95 && r_lo <= c.r[i] &&
+            c.r[i] <= r_hi)
+            mc.good.push_back(i);
+    }
+}
+
+// All of "while self.merge_arcs(arcs): ..." (reference tracker.py:964-965,
+// 1126-1286).  The good-tag lists and frame ranges the reference recomputes
+// for every pair are cached per arc and refreshed only for the arc a merger
+// changed; decisions and their order are unchanged.
+int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
+    const double maxd = c.p.max_distance_pixels;
+    const Rot rot = rotation(c);
+    std::vector<double> dist;
+    std::vector<long> off;
+    int rc = em_member_distances(c, stream, dist, off);
+    if (rc != HK_OK) return rc;
+    std::vector<MergeCache> cache(c.arcs.size());
+    for (size_t k = 0; k < c.arcs.size(); ++k)
+        refresh_cache(c, c.arcs[k], rot, dist.data() + off[k], cache[k]);
+
+    auto tw_of = [&](int i) { return c.tw[i]; };
+    std::vector<int> trial_tags;
+    bool merged = true;
+    while (merged) {                    // one iteration = one merge_arcs()
+        merged = false;
+        for (size_t i1 = 0; i1 < c.arcs.size() && !merged; ++i1) {
+            Arc &a1 = c.arcs[i1];
+            if (a1.done) continue;
+            if (a1.tags.empty() || cache[i1].good.size() < 3) {
+                a1.done = true;
+                continue;
+            }
+            for (size_t i2 = 0; i2 < c.arcs.size(); ++i2) {
+                if (i2 == i1) continue;
+                Arc &a2 = c.arcs[i2];
+                if (a2.tags.empty()) {
+                    a2.done = true;
+                    continue;
+                }
+                if (cache[i2].f_max < cache[i1].f_min ||
+                    cache[i2].f_min > cache[i1].f_max)
+                    continue;
+                if (cache[i2].good.size() < 3) continue;
+                trial_tags.clear();
+                std::set_union(cache[i1].good.begin(), cache[i1].good.end(),
+                               cache[i2].good.begin(), cache[i2].good.end(),
+                               std::back_inserter(trial_tags));
+                if ((int)trial_tags.size() < c.p.min_tags_per_arc) continue;
+                Arc trial = a1;
+                fit_one(c, trial, trial_tags, rot, tw_of);
+                int poor = 0;
+                for (int t : trial_tags)
+                    if (arc_tag_distance(c, trial, rot, t) > maxd) ++poor;
+                if (poor > 2) continue;
+
+                // merge a2 into a1
+                a1.a = trial.a;
+                a1.b = trial.b;
+                a1.c = trial.c;
+                a1.e = trial.e;
+                a1.f_peak = trial.f_peak;
+                a1.tags = trial_tags;
+                a1.w_off = -1;
+                refresh_cache(c, a1, rot, nullptr, cache[i1]);
+                c.arcs.erase(c.arcs.begin() + (long)i2);
+                cache.erase(cache.begin() + (long)i2);
+                merged = true;
+                merged_any = true;
+                break;
+            }
+            if (!merged) {
+                c.arcs[i1].done = true;
+                rc = report_progress(c);
+                if (rc != HK_OK) return rc;
+            }
+        }
+    }
+    return HK_OK;
+}
+
+// All of "while self.prune_arcs(arcs): ..." (reference tracker.py:969-970,
+// 1288-1329): arcs do not change between passes, so every failing arc goes.
+int prune_phase(hk_clip &c, hipStream_t stream, bool &pruned_any) {
+    std::vector<double> dist;
+    std::vector<long> off;
+    const int rc = em_member_distances(c, stream, dist, off);
+    if (rc != HK_OK) return rc;
+    std::vector<Arc> kept;
+    kept.reserve(c.arcs.size());
+    for (size_t k = 0; k < c.arcs.size(); ++k) {
+        const Arc &arc = c.arcs[k];
+        int code = 0;
+        if (std::isnan(arc.a) || std::isnan(arc.b) || std::isnan(arc.c) ||
+            std::isnan(arc.e) || std::isnan(arc.f_peak)) {
+            code = 1;
+        } else if (arc.tags.empty()) {
+            code = 5;
+        } else if (!acceleration_ok(c, arc.e)) {
+            code = 4;
+        } else {
+            int close = 0;
+            for (size_t j = 0; j < arc.tags.size(); ++j)
+                if (dist[off[k] + (long)j] < c.p.max_distance_pixels) ++close;
+            if (close < c.p.min_tags_per_arc) code = 2;
+        }
+        if (code == 0) {
+            kept.push_back(arc);
+        } else {
+            pruned_any = true;
+            const int prc = report_progress(c);
+            if (prc != HK_OK) return prc;
+        }
+    }
+    c.arcs.swap(kept);
+    return HK_OK;
+}
+
+// clean_notes (reference tracker.py:1331-1422).
+int clean(hk_clip &c) {
+    const double maxd = c.p.max_distance_pixels;
+    const Rot rot = rotation(c);
+    const size_t A = c.arcs.size();
+    // tag.weight keys, in arc-list order
+    std::vector<std::vector<int>> tag_arcs(c.n);
+    for (size_t k = 0; k < A; ++k)
+        for (int i : c.arcs[k].tags) tag_arcs[i].push_back((int)k);
+    std::vector<char> tag_done(c.n, 0), arc_dead(A, 0), arc_done(A, 0);
+
+    bool again = true;
+    while (again) {
+        for (int i = 0; i < c.n; ++i) {
+            if (!c.alive[i] || tag_done[i]) continue;
+            bool good = false;
+            for (int k : tag_arcs[i])
+                if (!arc_dead[k] &&
+                    arc_tag_distance(c, c.arcs[k], rot, i) < maxd) {
+                    good = true;
+                    break;
+                }
+            if (good) {
+                tag_done[i] = 1;
+                continue;
+            }
+            c.alive[i] = 0;
+            for (int k : tag_arcs[i]) {
+                if (arc_dead[k]) continue;
+                std::vector<int> &tg = c.arcs[k].tags;
+                const auto it = std::lower_bound(tg.begin(), tg.end(), i);
+                if (it != tg.end() && *it == i) tg.erase(it);
+                arc_done[k] = 0;
+            }
+        }
+        const int rc = report_progress(c);
+        if (rc != HK_OK) return rc;
+        again = false;
+        for (size_t k = 0; k < A; ++k) {
+            if (arc_dead[k] || arc_done[k]) continue;
+            if (eval_arc_host(c, c.arcs[k], rot, true, true) > 0) {
+                arc_dead[k] = 1;
+                for (int i : c.arcs[k].tags) tag_done[i] = 0;
+                again = true;
+            } else {
+                arc_done[k] = 1;
+            }
+        }
+    }
+
+    // final hard assignment: nearest arc among the tag's weight keys
+    std::vector<int> new_index(A, -1);
+    std::vector<Arc> kept;
+    for (size_t k = 0; k < A; ++k) {
+        if (arc_dead[k]) continue;
+        new_index[k] = (int)kept.size();
+        kept.push_back(c.arcs[k]);
+        kept.back().tags.clear();
+        kept.back().w_off = -1;
+        kept.back().done = false;
+    }
+    std::fill(c.final_arc.begin(), c.final_arc.end(), -1);
+    for (int i = 0; i < c.n; ++i) {
+        if (!c.alive[i]) continue;
+        int best = -1;
+        double best_d = 0;
+        for (int k : tag_arcs[i]) {
+            if (arc_dead[k]) continue;
+            const double d = arc_tag_distance(c, c.arcs[k], rot, i);
+            if (best < 0 || d < best_d) {
+                best = k;
+                best_d = d;
+            }
+        }
+        if (best < 0)
+            return fail(HK_ERR_INTERNAL, "clean: surviving tag without arc");
+        c.final_arc[i] = new_index[best];
+        kept[new_index[best]].tags.push_back(i);
+    }
+    c.arcs.swap(kept);
+    return HK_OK;
+}
+
+void sort_arcs_by_peak(hk_clip &c) {
+    const size_t A = c.arcs.size();
+    std::vector<int> order(A);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int p, int q) {
+        return c.arcs[p].f_peak < c.arcs[q].f_peak;
+    });
+    std::vector<int> where(A);
+    std::vector<Arc> sorted;
+    sorted.reserve(A);
+    for (size_t k = 0; k < A; ++k) {
+        where[order[k]] = (int)k;
+        sorted.push_back(std::move(c.arcs[order[k]]));
+    }
+    c.arcs.swap(sorted);
+    for (int &fa : c.final_arc)
+        if (fa >= 0) fa = where[fa];
+}
+
+}  // namespace
+
+}  // namespace hk
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+using hk::Arc;
+
+extern "C" int hk_scan_params_default(hk_scan_params *p, int frame_height,
+                                      int scan_height, double fps) {
+    if (!p || frame_height <= 0 || scan_height <= 0)
+        return hk::fail(HK_ERR_ARG, "hk_scan_params_default: bad argument");
+    p->sigmasq = 15.0;
+    p->max_frame_gap_in_arc = 2;
+    p->g_window = 0.25;
+    p->min_tags_to_curve_fit = 4;
+    p->default_frame_height_cm = 300;
+    p->max_frame_height_cm = 1000;
+    p->default_fps = 30;
+    p->max_fps = 60;
+    p->min_tags_per_arc = fps >= 29 ? 10 : 5;
+    p->max_distance_pixels = 5.0 * frame_height / 480;
+    p->radius_window = scan_height >= 480 ? 0.65 : 0.75;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_create(int frame_width, int frame_height, double fps,
+                              int frame_count, const hk_scan_params *params,
+                              int ntags, const int *frame, const double *x,
+                              const double *y, const double *radius,
+                              const double *total_weight, int device,
+                              hk_clip **out) {
+    if (!out || !params || frame_width <= 0 || frame_height <= 0 ||
+        frame_count < 0 || ntags < 0 || !(fps > 0))
+        return hk::fail(HK_ERR_ARG, "hk_clip_create: bad argument");
+    if (ntags > 0 && (!frame || !x || !y || !radius || !total_weight))
+        return hk::fail(HK_ERR_ARG, "hk_clip_create: null event array");
+    for (int i = 0; i < ntags; ++i) {
+        if (frame[i] < 0 || frame[i] >= frame_count ||
+            (i > 0 && frame[i] < frame[i - 1]))
+            return hk::fail(HK_ERR_ARG,
+                            "hk_clip_create: frame[] must be ascending within "
+                            "[0, frame_count); entry %d is %d", i, frame[i]);
+    }
+    hk_clip *c = new hk_clip();
+    c->W = frame_width;
+    c->H = frame_height;
+    c->F = frame_count;
+    c->fps = fps;
+    c->p = *params;
+    c->n = ntags;
+    c->frame.assign(frame, frame + ntags);
+    c->x.assign(x, x + ntags);
+    c->y.assign(y, y + ntags);
+    c->r.assign(radius, radius + ntags);
+    c->tw.assign(total_weight, total_weight + ntags);
+    c->start.assign((size_t)frame_count + 1, 0);
+    for (int i = 0; i < ntags; ++i) ++c->start[(size_t)frame[i] + 1];
+    for (int f = 0; f < frame_count; ++f) c->start[f + 1] += c->start[f];
+    c->alive.assign(ntags, 1);
+    c->final_arc.assign(ntags, -1);
+    c->device = device;
+    *out = c;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_destroy(hk_clip *c) {
+    if (!c) return HK_OK;
+    hk::em_release(*c);
+    delete c;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_set_progress(hk_clip *c, hk_progress_fn fn,
+                                    void *user) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_set_progress: null clip");
+    c->progress = fn;
+    c->progress_user = user;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_set_state(hk_clip *c, double camera_tilt, int has_g,
+                                 double g) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_set_state: null clip");
+    c->tilt = camera_tilt;
+    c->has_g = has_g != 0;
+    c->g = has_g ? g : 0.0;
+    if (has_g) c->cm_per_pixel = 980.7 / (g * (c->fps * c->fps));
+    return HK_OK;
+}
+
+extern "C" int hk_clip_get_state(const hk_clip *c, double *camera_tilt,
+                                 int *has_g, double *g, double *cm_per_pixel) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_get_state: null clip");
+    if (camera_tilt) *camera_tilt = c->tilt;
+    if (has_g) *has_g = c->has_g ? 1 : 0;
+    if (g) *g = c->g;
+    if (cm_per_pixel) *cm_per_pixel = c->cm_per_pixel;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_set_arcs(hk_clip *c, int narcs, const double *params5,
+                                const int *ids, const int *tag_offsets,
+                                const int *tag_index) {
+    if (!c || narcs < 0 || (narcs > 0 && (!params5 || !tag_offsets)))
+        return hk::fail(HK_ERR_ARG, "hk_clip_set_arcs: bad argument");
+    std::vector<Arc> arcs((size_t)narcs);
+    for (int k = 0; k < narcs; ++k) {
+        Arc &a = arcs[k];
+        a.a = params5[5 * k];
+        a.b = params5[5 * k + 1];
+        a.c = params5[5 * k + 2];
+        a.e = params5[5 * k + 3];
+        a.f_peak = params5[5 * k + 4];
+        a.id = ids ? ids[k] : k + 1;
+        const int lo = tag_offsets[k], hi = tag_offsets[k + 1];
+        if (lo < 0 || hi < lo || (hi > lo && !tag_index))
+            return hk::fail(HK_ERR_ARG, "hk_clip_set_arcs: bad offsets");
+        a.tags.assign(tag_index + lo, tag_index + hi);
+        for (int i : a.tags)
+            if (i < 0 || i >= c->n)
+                return hk::fail(HK_ERR_ARG,
+                                "hk_clip_set_arcs: tag index %d out of range",
+                                i);
+        std::sort(a.tags.begin(), a.tags.end());
+        a.tags.erase(std::unique(a.tags.begin(), a.tags.end()), a.tags.end());
+    }
+    c->arcs.swap(arcs);
+    return HK_OK;
+}
+
+extern "C" int hk_clip_arc_count(const hk_clip *c) {
+    return c ? (int)c->arcs.size() : 0;
+}
+
+extern "C" int hk_clip_arc_tag_total(const hk_clip *c) {
+    if (!c) return 0;
+    size_t n = 0;
+    for (const Arc &a : c->arcs) n += a.tags.size();
+    return (int)n;
+}
+
+extern "C" int hk_clip_get_arcs(const hk_clip *c, double *params5, int *ids,
+                                int *tag_offsets, int *tag_index) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_get_arcs: null clip");
+    int pos = 0;
+    for (size_t k = 0; k < c->arcs.size(); ++k) {
+        const Arc &a = c->arcs[k];
+        if (params5) {
+            params5[5 * k] = a.a;
+            params5[5 * k + 1] = a.b;
+            params5[5 * k + 2] = a.c;
+            params5[5 * k + 3] = a.e;
+            params5[5 * k + 4] = a.f_peak;
+        }
+        if (ids) ids[k] = a.id;
+        if (tag_offsets) tag_offsets[k] = pos;
+        if (tag_index)
+            std::copy(a.tags.begin(), a.tags.end(), tag_index + pos);
+        pos += (int)a.tags.size();
+    }
+    if (tag_offsets) tag_offsets[c->arcs.size()] = pos;
+    return HK_OK;
+}
+
+extern "C" int hk_clip_get_tag_state(const hk_clip *c, unsigned char *alive,
+                                     int *final_arc) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_get_tag_state: null clip");
+    for (int i = 0; i < c->n; ++i) {
+        if (alive) alive[i] = (unsigned char)c->alive[i];
+        if (final_arc) final_arc[i] = c->final_arc[i];
+    }
+    return HK_OK;
+}
+
+extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_build_initial_arcs: null");
+    std::vector<Arc> arcs;
+    {   // trial pass: a few confident arcs to estimate gravity
+        hk::ArcBuilder b(*c);
+        const int rc = b.construct(5, arcs);
+        if (rc != HK_OK) return rc;
+        hk::find_global_params(*c, arcs);
+    }
+    arcs.clear();
+    {
+        hk::ArcBuilder b(*c);
+        const int rc = b.construct(0, arcs);
+        if (rc != HK_OK) return rc;
+        hk::find_global_params(*c, arcs);
+    }
+    std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
+        return p.f_peak < q.f_peak;
+    });
+    for (size_t k = 0; k < arcs.size(); ++k) {
+        arcs[k].id = (int)k + 1;
+        arcs[k].w_off = -1;
+        arcs[k].done = false;
+    }
+    c->arcs.swap(arcs);
+    return HK_OK;
+}
+
+extern "C" int hk_clip_em_optimize(hk_clip *c, void *stream) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_em_optimize: null clip");
+    const hipStream_t s = (hipStream_t)stream;
+    int rc = hk::em_prepare(*c);
+    if (rc != HK_OK) return rc;
+    bool again = true;
+    while (again) {
+        if ((rc = hk::em_tilt(*c, s)) != HK_OK) return rc;
+        if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+        again = false;
+        for (Arc &a : c->arcs) a.done = false;
+        if ((rc = hk::merge_phase(*c, s, again)) != HK_OK) return rc;
+        if ((rc = hk::prune_phase(*c, s, again)) != HK_OK) return rc;
+        if ((rc = hk::em_estep(*c, s)) != HK_OK) return rc;
+        if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+    }
+    if ((rc = hk::clean(*c)) != HK_OK) return rc;
+    if ((rc = hk::em_tilt(*c, s)) != HK_OK) return rc;
+    if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+    hk::sort_arcs_by_peak(*c);
+    return HK_OK;
+}
+
+extern "C" int hk_clip_calculate_weights(hk_clip *c, void *stream) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_calculate_weights: null");
+    const int rc = hk::em_prepare(*c);
+    if (rc != HK_OK) return rc;
+    return hk::em_estep(*c, (hipStream_t)stream);
+}
+
+extern "C" int hk_clip_fit_arcs(hk_clip *c, void *stream) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_fit_arcs: null clip");
+    const int rc = hk::em_prepare(*c);
+    if (rc != HK_OK) return rc;
+    return hk::em_fit(*c, (hipStream_t)stream);
+}
+
+extern "C" int hk_clip_estimate_camera_tilt(hk_clip *c, void *stream) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_estimate_camera_tilt: null");
+    const int rc = hk::em_prepare(*c);
+    if (rc != HK_OK) return rc;
+    return hk::em_tilt(*c, (hipStream_t)stream);
+}
+
+extern "C" int hk_clip_eval_arc(hk_clip *c, int index, int requirepeak,
+                                int checkaccel) {
+    if (!c || index < 0 || index >= (int)c->arcs.size())
+        return hk::fail(HK_ERR_ARG, "hk_clip_eval_arc: bad arc index");
+    return hk::eval_arc_host(*c, c->arcs[index], hk::rotation(*c),
+                             requirepeak != 0, checkaccel != 0);
+}
+
+extern "C" int hk_clip_member_distances(hk_clip *c, double *dist,
+                                        void *stream) {
+    if (!c || !dist)
+        return hk::fail(HK_ERR_ARG, "hk_clip_member_distances: null");
+    int rc = hk::em_prepare(*c);
+    if (rc != HK_OK) return rc;
+    std::vector<double> d;
+    std::vector<long> off;
+    rc = hk::em_member_distances(*c, (hipStream_t)stream, d, off);
+    if (rc != HK_OK) return rc;
+    std::copy(d.begin(), d.end(), dist);
+    return HK_OK;
+}

@@ -164,3 +164,105 @@ def tags_to_soa(meas, frame_count=None):
             k += 1
     start[frame_count] = k
     return frame, x, y, r, np.ones(n, np.float64), start
+
+
+# ---------------------------------------------------------------------------
+# rendered clips (SURVEY.md §8d configurations)
+# ---------------------------------------------------------------------------
+
+CLIPS = {
+    # name: width, height, fps, balls, frames, ball radius, noise sigma,
+    #       drift amplitude / Hz, distractors, seed
+    'B_720p30_5ball': dict(width=1280, height=720, fps=30.0, balls=5,
+                           frames=900, ball_r=8.0, sigma=2.0, drift=0.0,
+                           drift_hz=0.0, distractors=0, seed=1001),
+    'C_1080p60_9ball_noisy': dict(width=1920, height=1080, fps=60.0, balls=9,
+                                  frames=1800, ball_r=10.0, sigma=4.0,
+                                  drift=8.0, drift_hz=0.2, distractors=20,
+                                  seed=1002),
+    'D_4k240_9ball_long': dict(width=3840, height=2160, fps=240.0, balls=9,
+                               frames=14400, ball_r=16.0, sigma=3.0,
+                               drift=0.0, drift_hz=0.0, distractors=0,
+                               seed=1003),
+}
+
+
+def clip_E(i):
+    """Clip i of configuration E: 64 clips 1920x1080@60, 600 frames, 3..9
+    balls cycling, seeds 2000+i."""
+    return dict(width=1920, height=1080, fps=60.0, balls=3 + i % 7,
+                frames=600, ball_r=10.0, sigma=3.0, drift=0.0, drift_hz=0.0,
+                distractors=0, seed=2000 + i)
+
+
+MAX_DISCS = 40
+
+
+def disc_lists(spec, scene=None):
+    """float32 [frames][MAX_DISCS][4] = (x, y, radius, kind) per frame:
+    balls of the juggling scene (kind 0) plus random-walk distractor blobs
+    with radii in [2, 14] (kinds 1-3)."""
+    if scene is None:
+        scene = JugglingScene(spec['width'], spec['height'], spec['fps'],
+                              spec['balls'], spec['frames'], spec['seed'])
+    F = spec['frames']
+    out = np.zeros((F, MAX_DISCS, 4), np.float32)
+    rng = np.random.RandomState(spec['seed'] + 7)
+    nd = spec['distractors']
+    if nd:
+        pos = np.stack([rng.uniform(0, spec['width'], nd),
+                        rng.uniform(0, spec['height'], nd)], 1)
+        rad = rng.uniform(2.0, 14.0, nd)
+        kind = 1 + rng.randint(0, 3, nd)
+        vel = rng.normal(0, 1.0, (nd, 2))
+    for f in range(F):
+        k = 0
+        for (x, y) in scene.ball_positions(f):
+            if k < MAX_DISCS - nd:
+                out[f, k] = (x, y, spec['ball_r'], 0)
+                k += 1
+        if nd:
+            vel = 0.95 * vel + rng.normal(0, 0.35, (nd, 2))
+            pos = pos + vel
+            pos[:, 0] %= spec['width']
+            pos[:, 1] %= spec['height']
+            out[f, MAX_DISCS - nd:, 0:2] = pos
+            out[f, MAX_DISCS - nd:, 2] = rad
+            out[f, MAX_DISCS - nd:, 3] = kind
+    return out
+
+
+class ClipRenderer:
+    """Renders frames of one synthetic clip on the device (uint8 BGR)."""
+
+    def __init__(self, spec, device=0, juggler=True):
+        import torch
+        from . import _native as nat
+        self._nat, self._torch = nat, torch
+        self.spec = dict(spec)
+        self.device = torch.device('cuda', device)
+        self.scene = JugglingScene(spec['width'], spec['height'], spec['fps'],
+                                   spec['balls'], spec['frames'], spec['seed'])
+        self.discs = torch.from_numpy(disc_lists(spec, self.scene)).to(
+            self.device)
+        self.juggler = 1 if juggler else 0
+
+    def render(self, first, count, out=None):
+        """Frames [first, first+count) as a uint8 tensor [count][H][W][3]."""
+        torch, nat, s = self._torch, self._nat, self.spec
+        if first < 0 or first + count > s['frames']:
+            raise ValueError('frame range outside the clip')
+        if out is None:
+            out = torch.empty((count, s['height'], s['width'], 3),
+                              dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        done = 0
+        while done < count:         # grid.z limit
+            n = min(count - done, 4096)
+            nat.check(nat.lib.hk_render_frames(
+                s['width'], s['height'], s['fps'], s['seed'], s['sigma'],
+                s['drift'], s['drift_hz'], self.juggler,
+                self.discs.data_ptr(), MAX_DISCS, first + done, n,
+                out[done].data_ptr(), out.stride(0), out.stride(1), stream))
+            done += n
+        return out

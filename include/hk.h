@@ -144,6 +144,114 @@ int hk_blob_detect(hk_blob *b, const void *mask_dev, long frame_stride,
 int hk_blob_finish_centers(hk_blob *b, int *counts_host, double *centers_host,
                            int cap, int *total);
 
+/* ------------------------------------------------------------------------
+ * H1  synthetic frames (input generation for tests and benchmarks; the
+ *     reference ships no clips, reference README.md:25-27).  Renders frames
+ *     first_frame .. first_frame+nframes-1 of a scene into bgr_dev: gradient +
+ *     fixed texture background, optional brightness drift, optional dark
+ *     "juggler" rectangle, the discs listed per frame in discs_dev
+ *     (float [total_frames][max_discs][4] = x, y, radius, kind; radius <= 0
+ *     = unused; indexed by absolute frame number) and Gaussian sensor noise.
+ *     Deterministic in (seed, frame, pixel).  Enqueues on `stream`.
+ * ---------------------------------------------------------------------- */
+int hk_render_frames(int width, int height, float fps, unsigned seed,
+                     float noise_sigma, float drift_amp, float drift_hz,
+                     int juggler, const float *discs_dev, int max_discs,
+                     int first_frame, int nframes, void *bgr_dev,
+                     long frame_stride, long pitch, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Steps 3-4: preliminary arcs and EM refinement on the detected events
+ *     replaces VideoScanner.build_initial_arcs()   (reference tracker.py:450-696,
+ *     880-906) and VideoScanner.EM_optimize()      (reference tracker.py:912-1435).
+ *
+ * A "clip" holds the events of one video as SoA arrays in (frame, position
+ * in notes['meas'][frame]) order.  Step 3 is host code.  Step 4 keeps the
+ * reference's merge / prune / clean control flow on the host and runs
+ *   K5 E-step      calculate_weights   (reference tracker.py:992-1039)
+ *   K6 M-step      fit_arcs            (reference tracker.py:698-798)
+ *      tilt        estimate_camera_tilt (reference tracker.py:1041-1124)
+ *   K7 distances   Ballarc.get_distance_from_tag over arc members
+ *                                      (reference types.py:70-72)
+ * as fp64 HIP kernels on `device`, one wavefront per arc.
+ * ---------------------------------------------------------------------- */
+typedef struct hk_scan_params {
+    /* reference tracker.py:2510-2570 (constants) */
+    double sigmasq;
+    int max_frame_gap_in_arc;
+    double g_window;
+    int min_tags_to_curve_fit;
+    double default_frame_height_cm;
+    double max_frame_height_cm;
+    double default_fps;
+    double max_fps;
+    /* reference tracker.py:345-355 (derived in step 2) */
+    int min_tags_per_arc;
+    double max_distance_pixels;
+    double radius_window;
+} hk_scan_params;
+
+/* Defaults of reference default_scanner_params() with the step-2 derived keys
+ * for a source video of frame_height at fps scanned at scan_height. */
+int hk_scan_params_default(hk_scan_params *p, int frame_height,
+                           int scan_height, double fps);
+
+/* Called from inside long loops on the calling thread; a non-zero return
+ * aborts the step with HK_ERR_ABORTED (mirrors callback() in reference
+ * tracker.py:630-631, 1283-1284, 1325-1326, 1375-1376). */
+typedef int (*hk_progress_fn)(void *user);
+
+typedef struct hk_clip hk_clip;
+
+/* Copies the events.  frame[] must be ascending in [0, frame_count).
+ * No HIP call is made until a step-4 function runs. */
+int hk_clip_create(int frame_width, int frame_height, double fps,
+                   int frame_count, const hk_scan_params *params, int ntags,
+                   const int *frame, const double *x, const double *y,
+                   const double *radius, const double *total_weight,
+                   int device, hk_clip **out);
+int hk_clip_destroy(hk_clip *c);
+int hk_clip_set_progress(hk_clip *c, hk_progress_fn fn, void *user);
+
+/* notes['camera_tilt'] and notes['g_px_per_frame_sq'] (has_g = key present). */
+int hk_clip_set_state(hk_clip *c, double camera_tilt, int has_g, double g);
+int hk_clip_get_state(const hk_clip *c, double *camera_tilt, int *has_g,
+                      double *g, double *cm_per_pixel);
+
+/* notes['arcs']: params5 = (a, b, c, e, f_peak) per arc; members of arc i are
+ * tag_index[tag_offsets[i] .. tag_offsets[i+1]).  Weights are 1.0, as after
+ * step 3. */
+int hk_clip_set_arcs(hk_clip *c, int narcs, const double *params5,
+                     const int *ids, const int *tag_offsets,
+                     const int *tag_index);
+int hk_clip_arc_count(const hk_clip *c);
+int hk_clip_arc_tag_total(const hk_clip *c);
+int hk_clip_get_arcs(const hk_clip *c, double *params5, int *ids,
+                     int *tag_offsets, int *tag_index);
+/* alive[i] = 0 for events removed by clean_notes; final_arc[i] = index of
+ * tag.arc in the arc list, or -1. */
+int hk_clip_get_tag_state(const hk_clip *c, unsigned char *alive,
+                          int *final_arc);
+
+/* Step 3 (host only). */
+int hk_clip_build_initial_arcs(hk_clip *c);
+/* Step 4.  Synchronises `stream` as needed. */
+int hk_clip_em_optimize(hk_clip *c, void *stream);
+
+/* The individual EM operations, as VideoScanner exposes them. */
+int hk_clip_calculate_weights(hk_clip *c, void *stream);
+int hk_clip_fit_arcs(hk_clip *c, void *stream);
+int hk_clip_estimate_camera_tilt(hk_clip *c, void *stream);
+/* Normalised E-step weights as (tag, arc index, weight) triples in arc order,
+ * after hk_clip_calculate_weights.  Returns the count (may exceed cap). */
+int hk_clip_get_weights(hk_clip *c, int *tag, int *arc, double *weight,
+                        int cap, void *stream);
+/* eval_arc() failure code of arc `index` (reference tracker.py:800-840). */
+int hk_clip_eval_arc(hk_clip *c, int index, int requirepeak, int checkaccel);
+/* Distances of every arc's members to the arc (K7), laid out like
+ * hk_clip_get_arcs' tag_index. */
+int hk_clip_member_distances(hk_clip *c, double *dist, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,98 @@
+"""
+CPU: native step 3 (host C++ behind the C ABI, no GPU involved) against the
+golden runs produced by the reference, and against the Python oracle on a
+fresh seeded input.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hawkeye_amd import synth
+from hawkeye_amd.arcs import Clip
+
+RUNS = ['clean_720p30_5ball', 'noisy_1080p60_9ball', 'tilt3_720p30_5ball',
+        'lowfps_480p24_3ball']
+REL = 1e-6      # see tests/test_oracle_em.py for why not tighter
+
+
+def close(a, b, rel=REL, abs_=1e-9):
+    return abs(a - b) <= abs_ + rel * max(abs(a), abs(b))
+
+
+def load_run(golden_dir, name):
+    with open(os.path.join(golden_dir, 'run_{}.json'.format(name))) as fh:
+        run = json.load(fh)
+    meas = {int(f): [tuple(t) for t in lst] for f, lst in run['meas'].items()}
+    return run, meas
+
+
+def make_clip(run, meas, **kw):
+    frame, x, y, r, tw, start = synth.tags_to_soa(meas, run['frames'])
+    clip = Clip(run['width'], run['height'], run['fps'], run['frames'], frame,
+                x, y, r, tw, **kw)
+    # (frame, index in frame) key of every tag, as the fixtures use
+    key = [(int(f), int(i - start[f])) for i, f in enumerate(frame)]
+    return clip, key
+
+
+@pytest.mark.parametrize('name', RUNS)
+def test_build_initial_arcs_matches_reference(golden_dir, name):
+    run, meas = load_run(golden_dir, name)
+    clip, key = make_clip(run, meas, stream=0)
+    clip.build_initial_arcs()
+    st = clip.state()
+    want = run['step3']
+    assert close(st['g_px_per_frame_sq'], want['g_px_per_frame_sq'])
+    assert close(st['cm_per_pixel'], want['cm_per_pixel'])
+    params, ids, tags = clip.arcs()
+    assert len(params) == len(want['arcs'])
+    for p, i, t, w in zip(params, ids, tags, want['arcs']):
+        assert i == w['id']
+        assert [list(key[j]) for j in t] == w['tags']
+        for got, k in zip(p, ('a', 'b', 'c', 'e', 'f_peak')):
+            assert close(got, w[k]), (k, i)
+
+
+def test_matches_oracle_on_new_input():
+    from oracle import em_ref
+    scene = synth.JugglingScene(960, 540, 50.0, 4, 150, 77)
+    meas = synth.make_tags(scene, 78, clutter_per_frame=5.0)
+    frame, x, y, r, tw, start = synth.tags_to_soa(meas, 150)
+    clip = Clip(960, 540, 50.0, 150, frame, x, y, r, tw, stream=0)
+    clip.build_initial_arcs()
+    sc = em_ref.Scene(meas, 960, 540, 50.0, frame_count=150)
+    sc.build_initial_arcs()
+    params, ids, tags = clip.arcs()
+    assert len(params) == len(sc.arcs) > 5
+    assert close(clip.state()['g_px_per_frame_sq'], sc.g)
+    for p, t, arc in zip(params, tags, sc.arcs):
+        assert list(t) == arc.tags
+        for got, want in zip(p, arc.params()):
+            assert close(got, want)
+
+
+def test_progress_callback_can_abort(golden_dir):
+    run, meas = load_run(golden_dir, 'noisy_1080p60_9ball')
+    clip, _ = make_clip(run, meas, stream=0)
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def cb():
+        calls.append(1)
+        if len(calls) == 3:
+            raise Stop('enough')
+    clip.set_progress(cb)
+    with pytest.raises(Stop):
+        clip.build_initial_arcs()
+    assert len(calls) == 3
+
+
+def test_rejects_unsorted_frames():
+    from hawkeye_amd import _native as nat
+    with pytest.raises(nat.NativeError, match='ascending'):
+        Clip(64, 48, 30.0, 10, [3, 2], [1.0, 2.0], [1.0, 2.0], [5.0, 5.0],
+             stream=0)
