@@ -193,3 +193,57 @@ class SimpleBlobDetector:
             self.enqueue(masks[s:s + self.max_frames])
             out.extend(self.finish())
         return out
+
+
+class EventDetector:
+    """Step-2 arithmetic for a stream of frame chunks: MOG -> blob detector.
+
+    ``submit(frames)`` enqueues MOG and blob detection for one chunk and
+    returns the per-frame keypoints of the *previous* chunk (two blob work
+    sets alternate, so the host-side grouping of chunk i overlaps the GPU work
+    of chunk i+1); ``flush()`` returns the last chunk's.  Results come back in
+    frame order: a list with one float32 [n][3] array (x, y, size) per frame.
+    """
+
+    def __init__(self, width, height, blob_params=None, chunk=128, device=0):
+        self.width, self.height, self.chunk = int(width), int(height), \
+            int(chunk)
+        self.device = torch.device('cuda', device)
+        self.mog = BackgroundSubtractorMOG(width, height, device)
+        self.blob = [SimpleBlobDetector(width, height, blob_params,
+                                        max_frames=self.chunk, device=device)
+                     for _ in range(2)]
+        self.masks = [torch.empty((self.chunk, self.height, self.width),
+                                  dtype=torch.uint8, device=self.device)
+                      for _ in range(2)]
+        self._cur = 0
+        self._pending = [False, False]
+
+    def submit(self, frames):
+        t = frames.shape[0]
+        if t == 0 or t > self.chunk:
+            raise ValueError('chunk of {} frames (max {})'.format(t,
+                                                                   self.chunk))
+        p = self._cur
+        masks = self.masks[p][:t]
+        self.mog.apply_batch(frames, out=masks)
+        self.blob[p].enqueue(masks)
+        self._pending[p] = True
+        self._cur = 1 - p
+        return self._collect(1 - p)
+
+    def _collect(self, p):
+        if not self._pending[p]:
+            return []
+        self._pending[p] = False
+        return self.blob[p].finish()
+
+    def flush(self):
+        out = self._collect(self._cur)
+        out += self._collect(1 - self._cur)
+        return out
+
+    def close(self):
+        self.mog.close()
+        for b in self.blob:
+            b.close()

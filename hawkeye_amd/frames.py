@@ -1,0 +1,139 @@
+"""
+Frame sources for step 2.
+
+Video decode stays on the host and is out of scope (north_star); step 2 only
+needs "the next frames as BGR uint8 on the device".  A source exposes
+
+    fps, width, height, frame_count_estimate
+    read(max_frames) -> uint8 tensor [T][H][W][3] on the device, T == 0 at end
+
+``open_source(path)`` resolves, in order: a source registered for that path
+(``register_source``; how tests, benchmarks and host decoders hand frames in),
+then ``cv2.VideoCapture`` when OpenCV is importable (the reference's own
+decode path, reference tracker.py:262-271, 315-330, 383), else the same
+"Error opening video file" failure the reference raises.
+"""
+import os
+
+import numpy as np
+import torch
+
+_REGISTRY = {}
+
+
+def register_source(path, factory):
+    """Associate ``path`` (as given to VideoScanner) with a zero-argument
+    callable returning a fresh source."""
+    _REGISTRY[os.path.abspath(path)] = factory
+
+
+def unregister_source(path):
+    _REGISTRY.pop(os.path.abspath(path), None)
+
+
+class SourceError(Exception):
+    pass
+
+
+class ArraySource:
+    """Frames held in host (NumPy) or device (torch) memory."""
+
+    def __init__(self, frames, fps, device=0):
+        self.device = torch.device('cuda', device)
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or \
+                frames.shape[3] != 3:
+            raise ValueError('frames must be uint8 [T][H][W][3] (BGR)')
+        self._frames = frames
+        self.fps = float(fps)
+        self.frame_count_estimate = int(frames.shape[0])
+        self.height, self.width = int(frames.shape[1]), int(frames.shape[2])
+        self._pos = 0
+
+    def read(self, max_frames):
+        chunk = self._frames[self._pos:self._pos + max_frames]
+        self._pos += chunk.shape[0]
+        if chunk.device != self.device:
+            chunk = chunk.to(self.device, non_blocking=True)
+        return chunk
+
+    def close(self):
+        self._frames = None
+
+
+class SyntheticSource:
+    """A clip of hawkeye_amd.synth rendered on the device chunk by chunk."""
+
+    def __init__(self, spec, device=0, first=0, count=None):
+        from . import synth
+        self._renderer = synth.ClipRenderer(spec, device=device)
+        self.fps = float(spec['fps'])
+        self.width, self.height = spec['width'], spec['height']
+        self._first = first
+        self._end = spec['frames'] if count is None else first + count
+        self.frame_count_estimate = self._end - first
+        self._pos = first
+
+    def read(self, max_frames):
+        n = min(max_frames, self._end - self._pos)
+        if n <= 0:
+            return torch.empty((0, self.height, self.width, 3),
+                               dtype=torch.uint8,
+                               device=self._renderer.device)
+        out = self._renderer.render(self._pos, n)
+        self._pos += n
+        return out
+
+    def close(self):
+        self._renderer = None
+
+
+class OpenCVSource:
+    """cv2.VideoCapture decode on the host, uploaded in chunks."""
+
+    def __init__(self, path, device=0):
+        import cv2
+        self._cv2 = cv2
+        self.device = torch.device('cuda', device)
+        self._cap = cv2.VideoCapture(path)
+        if not self._cap.isOpened():
+            raise SourceError(path)
+        self.fps = self._cap.get(cv2.CAP_PROP_FPS)
+        self.frame_count_estimate = int(self._cap.get(
+            cv2.CAP_PROP_FRAME_COUNT))
+        self.width = int(self._cap.get(cv2.CAP_PROP_FRAME_WIDTH))
+        self.height = int(self._cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
+        self._reads = 0
+
+    def read(self, max_frames):
+        # same retry rule as reference tracker.py:382-392: failed reads are
+        # skipped until more reads than the estimated frame count were made
+        got = []
+        while len(got) < max_frames and self._cap.isOpened():
+            ok, frame = self._cap.read()
+            self._reads += 1
+            if not ok:
+                if self._reads > self.frame_count_estimate:
+                    break
+                continue
+            got.append(frame)
+        if not got:
+            return torch.empty((0, self.height, self.width, 3),
+                               dtype=torch.uint8, device=self.device)
+        host = torch.from_numpy(np.stack(got)).pin_memory()
+        return host.to(self.device, non_blocking=True)
+
+    def close(self):
+        self._cap.release()
+
+
+def open_source(path, device=0):
+    factory = _REGISTRY.get(os.path.abspath(path))
+    if factory is not None:
+        return factory()
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        raise SourceError(path)
+    return OpenCVSource(path, device=device)
