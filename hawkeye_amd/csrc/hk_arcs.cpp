@@ -14,6 +14,11 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <memory>
+#include <thread>
 
 #include "hk_clip.h"
 
@@ -208,175 +213,366 @@ int report_progress(hk_clip &c) {
 // step 3
 // ---------------------------------------------------------------------------
 
+// Worker threads for step 3.  The box's CPU share is what OMP_NUM_THREADS
+// says (the GPU boxes export 16); never more than 16.
+int worker_count() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("HK_THREADS")) n = atoi(e);
+    else if (const char *o = getenv("OMP_NUM_THREADS")) n = std::min(n, atoi(o));
+    return std::max(1, std::min(n, 16));
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+// construct_arcs (reference tracker.py:487-652).
+//
+// The reference walks the seed tags (top of the frame first) one at a time.
+// A seed changes shared state in exactly one of two ways: it fails, and only
+// marks itself done, or -- rarely -- it yields an arc and marks the arc's
+// members done.  So seeds are evaluated in batches, in parallel, each under
+// the assumption that every earlier seed of its batch fails; the results are
+// then committed in order, and the first accepted arc of a batch discards the
+// later (now possibly stale) results of that batch, which are re-run.  The
+// outcome is exactly the sequential one.
 class ArcBuilder {
 public:
     explicit ArcBuilder(hk_clip &c)
-        : c_(c), nb_(c.n), nb_ready_(c.n, 0), in_frontier_(c.n, 0),
-          taken_(c.F > 0 ? c.F : 1, 0) {
+        : c_(c), nb_(c.n), nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
+          done_(c.n, 0), batch_pos_(c.n, -1) {
+        for (int i = 0; i < c.n; ++i) nb_state_[i].store(0);
         has_vmax_ = c.has_g;
         if (has_vmax_) v_max_ = std::sqrt(2 * c.g * c.H);
+        maxd_ = c.p.max_distance_pixels;
+        rot_ = rotation(c);
+        if (c.has_g) {
+            e0_ = 0.5 * c.g;
+        } else {
+            const double cm_per_px = c.p.default_frame_height_cm / c.H;
+            e0_ = 0.5 * G_CM / (cm_per_px * (c.fps * c.fps));
+        }
+    }
+
+    int construct(int maxcount, std::vector<Arc> &out) {
+        hk_clip &c = c_;
+        std::vector<int> queue(c.n);
+        std::iota(queue.begin(), queue.end(), 0);
+        std::stable_sort(queue.begin(), queue.end(),
+                         [&](int p, int q) { return c.y[p] < c.y[q]; });
+
+        const int nthreads = worker_count();
+        nthreads_ = nthreads;
+        // the trial pass stops after a handful of arcs: keep its speculation
+        // shallow so that little work is thrown away
+        const size_t batch_max = maxcount > 0
+                                     ? (size_t)nthreads
+                                     : (size_t)std::max(8, 16 * nthreads);
+        std::vector<Scratch> scratch((size_t)nthreads);
+        for (Scratch &s : scratch) s.init(c.n, c.F);
+        results_.assign(batch_max, SeedResult());
+
+        // persistent workers, released phase by phase through `generation_`
+        generation_.store(0);
+        quit_.store(false);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t)
+            pool.emplace_back([this, &scratch, t] { worker_loop(scratch[t]); });
+
+        const int reach = c.p.max_frame_gap_in_arc + 1;
+        int rc = HK_OK;
+        size_t q = 0;
+        int since_progress = 0;
+        bool full = false;
+        std::vector<char> stale;
+        while (q < queue.size() && !full && rc == HK_OK) {
+            // next batch: seeds not yet done, in queue order
+            batch_.clear();
+            while (q < queue.size() && batch_.size() < batch_max) {
+                const int t1 = queue[q++];
+                if (!done_[t1]) batch_.push_back(t1);
+            }
+            if (batch_.empty()) break;
+            for (size_t k = 0; k < batch_.size(); ++k)
+                batch_pos_[batch_[k]] = (int)k;
+            todo_.resize(batch_.size());
+            std::iota(todo_.begin(), todo_.end(), 0);
+            stale.assign(batch_.size(), 0);
+            run_phase(scratch[0]);
+
+            // commit in order; an accepted arc makes stale every later result
+            // that looked at frames the arc's members live in
+            size_t k = 0;
+            while (k < batch_.size() && !full && rc == HK_OK) {
+                for (; k < batch_.size(); ++k) {
+                    const int t1 = batch_[k];
+                    if (done_[t1]) continue;    // joined an arc meanwhile
+                    if (stale[k]) break;
+                    SeedResult &r = results_[k];
+                    if (r.made) {
+                        int lo = c.frame[r.arc.tags.front()], hi = lo;
+                        for (int j : r.arc.tags) {
+                            done_[j] = 1;
+                            lo = std::min(lo, c.frame[j]);
+                            hi = std::max(hi, c.frame[j]);
+                        }
+                        out.push_back(std::move(r.arc));
+                        if (maxcount > 0 && (int)out.size() >= maxcount) {
+                            full = true;
+                            break;
+                        }
+                        for (size_t m = k + 1; m < batch_.size(); ++m)
+                            if (results_[m].lo - reach <= hi &&
+                                results_[m].hi + reach >= lo)
+                                stale[m] = 1;
+                    }
+                    done_[t1] = 1;
+                    if (++since_progress >= 256) {
+                        since_progress = 0;
+                        if ((rc = report_progress(c)) != HK_OK) break;
+                    }
+                }
+                if (full || rc != HK_OK || k >= batch_.size()) break;
+                // recompute the stale remainder (still "predecessors fail")
+                todo_.clear();
+                for (size_t m = k; m < batch_.size(); ++m)
+                    if (stale[m] && !done_[batch_[m]]) todo_.push_back((int)m);
+                std::fill(stale.begin(), stale.end(), 0);
+                run_phase(scratch[0]);
+            }
+            for (int t1 : batch_) batch_pos_[t1] = -1;
+        }
+
+        quit_.store(true);
+        generation_.fetch_add(1);
+        for (std::thread &t : pool) t.join();
+        return rc;
+    }
+
+private:
+    struct Scratch {
+        std::vector<int> in_frontier, taken, members, frontier, cand, order;
+        std::vector<double> vel;
+        int stamp = 0;
+        void init(int n, int F) {
+            in_frontier.assign((size_t)n, 0);
+            taken.assign((size_t)(F > 0 ? F : 1), 0);
+        }
+    };
+    struct alignas(64) SeedResult {     // one cache line each: no false sharing
+        bool made = false;
+        int lo = 0, hi = 0;     // frames of every tag the run put on a trial
+        Arc arc;
+    };
+
+    bool is_done(int j, int pos) const {
+        return done_[j] || (unsigned)batch_pos_[j] < (unsigned)pos;
     }
 
     // Neighbours of tag i: every tag within max_frame_gap_in_arc + 1 frames,
     // other frames only, ordered by the speed needed to get there (stable),
     // capped at v_max once g is known (reference tracker.py:654-696).  Built
-    // on first use; the reference builds all of them up front, which yields
-    // the same lists.
-    const std::vector<int> &neighbors(int i) {
-        if (nb_ready_[i]) return nb_[i];
-        const int f = c_.frame[i];
-        const int gap = c_.p.max_frame_gap_in_arc;
-        const int lo = std::max(0, f - gap - 1);
-        const int hi = std::min(c_.F, f + gap + 2);
-        cand_.clear();
-        vel_.clear();
-        for (int j = c_.start[lo]; j < c_.start[hi]; ++j) {
-            if (c_.frame[j] == f) continue;
-            const double dx = c_.x[j] - c_.x[i], dy = c_.y[j] - c_.y[i];
-            cand_.push_back(j);
-            vel_.push_back(std::sqrt(dx * dx + dy * dy) /
-                           std::abs(c_.frame[j] - f));
+    // on first use by whichever thread needs it; the reference builds all of
+    // them up front, which yields the same lists.
+    const std::vector<int> &neighbors(int i, Scratch &s) {
+        uint8_t st = nb_state_[i].load(std::memory_order_acquire);
+        if (st == 2) return nb_[i];
+        uint8_t expected = 0;
+        if (!nb_state_[i].compare_exchange_strong(expected, 1)) {
+            while (nb_state_[i].load(std::memory_order_acquire) != 2)
+                cpu_relax();
+            return nb_[i];
         }
-        order_.resize(cand_.size());
-        std::iota(order_.begin(), order_.end(), 0);
-        std::stable_sort(order_.begin(), order_.end(),
-                         [&](int p, int q) { return vel_[p] < vel_[q]; });
+        const hk_clip &c = c_;
+        const int f = c.frame[i];
+        const int gap = c.p.max_frame_gap_in_arc;
+        const int lo = std::max(0, f - gap - 1);
+        const int hi = std::min(c.F, f + gap + 2);
+        s.cand.clear();
+        s.vel.clear();
+        for (int j = c.start[lo]; j < c.start[hi]; ++j) {
+            if (c.frame[j] == f) continue;
+            const double dx = c.x[j] - c.x[i], dy = c.y[j] - c.y[i];
+            s.cand.push_back(j);
+            s.vel.push_back(std::sqrt(dx * dx + dy * dy) /
+                            std::abs(c.frame[j] - f));
+        }
+        s.order.resize(s.cand.size());
+        std::iota(s.order.begin(), s.order.end(), 0);
+        std::stable_sort(s.order.begin(), s.order.end(), [&](int p, int q) {
+            return s.vel[p] < s.vel[q];
+        });
         std::vector<int> &out = nb_[i];
-        out.reserve(order_.size());
-        for (int k : order_)
-            if (!has_vmax_ || vel_[k] <= v_max_) out.push_back(cand_[k]);
-        nb_ready_[i] = 1;
+        out.reserve(s.order.size());
+        for (int k : s.order)
+            if (!has_vmax_ || s.vel[k] <= v_max_) out.push_back(s.cand[k]);
+        nb_state_[i].store(2, std::memory_order_release);
         return out;
     }
 
-    int construct(int maxcount, std::vector<Arc> &out) {
-        hk_clip &c = c_;
-        const double maxd = c.p.max_distance_pixels;
-        const Rot rot = rotation(c);
-        std::vector<int> queue(c.n);
-        std::iota(queue.begin(), queue.end(), 0);
-        std::stable_sort(queue.begin(), queue.end(),
-                         [&](int p, int q) { return c.y[p] < c.y[q]; });
-        std::vector<char> done(c.n, 0);
-        double e0;
-        if (c.has_g) {
-            e0 = 0.5 * c.g;
-        } else {
-            const double cm_per_px = c.p.default_frame_height_cm / c.H;
-            e0 = 0.5 * G_CM / (cm_per_px * (c.fps * c.fps));
+    void add_to_frontier(const std::vector<int> &src, int pos, Scratch &s) {
+        for (int j : src) {
+            if (is_done(j, pos) || s.taken[c_.frame[j]] == s.stamp ||
+                s.in_frontier[j] == s.stamp)
+                continue;
+            s.in_frontier[j] = s.stamp;
+            s.frontier.push_back(j);
         }
+    }
+
+    // One seed: try its neighbours in order until one pair grows into an
+    // acceptable arc (reference tracker.py:521-625).
+    void run_seed(int t1, int pos, Scratch &s, SeedResult &res) {
+        const hk_clip &c = c_;
+        res.made = false;
+        int lo = c.frame[t1], hi = lo;
+        struct Publish {        // touched frame range, written once on exit
+            SeedResult &r; int &lo, &hi;
+            ~Publish() { r.lo = lo; r.hi = hi; }
+        } publish{res, lo, hi};
         auto unit = [](int) { return 1.0; };
-        std::vector<int> members, frontier;
-        int since_progress = 0;
+        const std::vector<int> &nb1 = neighbors(t1, s);
+        for (int t2 : nb1) {
+            if (is_done(t2, pos)) continue;
+            ++s.stamp;
+            Arc arc;
+            const int f1 = c.frame[t1], f2 = c.frame[t2];
+            std::vector<int> &members = s.members;
+            members.clear();
+            members.push_back(std::min(t1, t2));
+            members.push_back(std::max(t1, t2));
+            s.taken[f1] = s.stamp;
+            s.taken[f2] = s.stamp;
+            lo = std::min(lo, f2);
+            hi = std::max(hi, f2);
+            s.frontier.clear();
+            add_to_frontier(nb1, pos, s);
+            add_to_frontier(neighbors(t2, s), pos, s);
 
-        for (int t1 : queue) {
-            if (done[t1]) continue;
-            bool made = false;
-            // nb_ has one slot per tag from the start, so this reference
-            // stays valid while other tags' lists are built
-            const std::vector<int> &nb1 = neighbors(t1);
-            for (int t2 : nb1) {
-                if (done[t2]) continue;
-                ++stamp_;
-                Arc arc;
-                const int f1 = c.frame[t1], f2 = c.frame[t2];
-                members.clear();
-                members.push_back(std::min(t1, t2));
-                members.push_back(std::max(t1, t2));
-                taken_[f1] = stamp_;
-                taken_[f2] = stamp_;
-                frontier.clear();
-                add_to_frontier(nb1, done, frontier);
-                add_to_frontier(neighbors(t2), done, frontier);
+            arc.e = e0_;
+            arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
+                         0.5 * (f1 + f2);
+            const double dt1 = f1 - arc.f_peak;
+            arc.c = c.y[t1] - arc.e * (dt1 * dt1);
+            arc.b = (c.x[t1] - c.x[t2]) / (f1 - f2);
+            arc.a = c.x[t1] - arc.b * (f1 - arc.f_peak);
 
-                arc.e = e0;
-                arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
-                             0.5 * (f1 + f2);
-                const double dt1 = f1 - arc.f_peak;
-                arc.c = c.y[t1] - arc.e * (dt1 * dt1);
-                arc.b = (c.x[t1] - c.x[t2]) / (f1 - f2);
-                arc.a = c.x[t1] - arc.b * (f1 - arc.f_peak);
-
-                bool bad = false;
-                while (!frontier.empty()) {
-                    int best = -1;
-                    double best_d = 0;
-                    for (int j : frontier) {
-                        const double d = arc_tag_distance(c, arc, rot, j);
-                        if (best < 0 || d < best_d ||
-                            (d == best_d && j < best)) {
-                            best = j;
-                            best_d = d;
-                        }
+            bool bad = false;
+            while (!s.frontier.empty()) {
+                int best = -1;
+                double best_d = 0;
+                for (int j : s.frontier) {
+                    const double d = arc_tag_distance(c, arc, rot_, j);
+                    if (best < 0 || d < best_d || (d == best_d && j < best)) {
+                        best = j;
+                        best_d = d;
                     }
-                    if (best_d > maxd) break;
-                    members.insert(std::upper_bound(members.begin(),
-                                                    members.end(), best),
-                                   best);
-                    taken_[c.frame[best]] = stamp_;
-                    add_to_frontier(neighbors(best), done, frontier);
-                    frontier.erase(
-                        std::remove_if(frontier.begin(), frontier.end(),
-                                       [&](int j) {
-                                           return taken_[c.frame[j]] == stamp_;
-                                       }),
-                        frontier.end());
-                    if ((int)members.size() > c.p.min_tags_to_curve_fit)
-                        fit_one(c, arc, members, rot, unit);
-                    if (std::isnan(arc.e) || arc.e <= 0) {
-                        bad = true;
-                        break;
-                    }
+                }
+                if (best_d > maxd_) break;
+                members.insert(
+                    std::upper_bound(members.begin(), members.end(), best),
+                    best);
+                s.taken[c.frame[best]] = s.stamp;
+                lo = std::min(lo, c.frame[best]);
+                hi = std::max(hi, c.frame[best]);
+                add_to_frontier(neighbors(best, s), pos, s);
+                s.frontier.erase(
+                    std::remove_if(s.frontier.begin(), s.frontier.end(),
+                                   [&](int j) {
+                                       return s.taken[c.frame[j]] == s.stamp;
+                                   }),
+                    s.frontier.end());
+                bool refit = false;
+                if ((int)members.size() > c.p.min_tags_to_curve_fit) {
+                    fit_one(c, arc, members, rot_, unit);
+                    refit = true;
+                }
+                if (std::isnan(arc.e) || arc.e <= 0) {
+                    bad = true;
+                    break;
+                }
+                if (refit) {
                     for (int j : members)
-                        if (arc_tag_distance(c, arc, rot, j) > maxd) {
+                        if (arc_tag_distance(c, arc, rot_, j) > maxd_) {
                             bad = true;
                             break;
                         }
-                    if (bad) break;
                 }
-                if (!bad) {
-                    arc.tags = members;
-                    if (eval_arc_host(c, arc, rot, false, true) == 0) {
-                        for (int j : members) done[j] = 1;
-                        out.push_back(arc);
-                        made = true;
-                    }
+                // without a refit the arc is unchanged: the older members
+                // passed this test already and the new one has
+                // best_d <= maxd
+                if (bad) break;
+            }
+            if (!bad) {
+                arc.tags = members;
+                if (eval_arc_host(c, arc, rot_, false, true) == 0) {
+                    res.arc = std::move(arc);
+                    res.made = true;
+                    return;
                 }
-                if (made) break;
             }
-            if (maxcount > 0 && (int)out.size() >= maxcount) break;
-            if (++since_progress >= 256) {
-                since_progress = 0;
-                const int rc = report_progress(c);
-                if (rc != HK_OK) return rc;
-            }
-            done[t1] = 1;
         }
-        return HK_OK;
     }
 
-private:
-    void add_to_frontier(const std::vector<int> &src,
-                         const std::vector<char> &done,
-                         std::vector<int> &frontier) {
-        for (int j : src) {
-            if (done[j] || taken_[c_.frame[j]] == stamp_ ||
-                in_frontier_[j] == stamp_)
-                continue;
-            in_frontier_[j] = stamp_;
-            frontier.push_back(j);
+    // Runs the seeds listed in todo_ (positions in batch_) on all threads.
+    void drain(Scratch &s) {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= todo_.size()) break;
+            const int k = todo_[i];
+            run_seed(batch_[(size_t)k], k, s, results_[(size_t)k]);
+        }
+        finished_.fetch_add(1, std::memory_order_release);
+    }
+
+    void run_phase(Scratch &mine) {
+        if (todo_.empty()) return;
+        next_.store(0);
+        finished_.store(0);
+        const bool threaded = nthreads_ > 1 && todo_.size() > 1;
+        if (threaded) generation_.fetch_add(1);     // release the workers
+        drain(mine);
+        if (threaded)
+            while (finished_.load(std::memory_order_acquire) < nthreads_)
+                cpu_relax();
+    }
+
+    void worker_loop(Scratch &s) {
+        unsigned seen = 0;
+        for (;;) {
+            unsigned g;
+            int spins = 0;
+            while ((g = generation_.load(std::memory_order_acquire)) == seen) {
+                if (++spins > 4000) {
+                    std::this_thread::yield();
+                    spins = 0;
+                } else {
+                    cpu_relax();
+                }
+            }
+            seen = g;
+            if (quit_.load()) return;
+            drain(s);
         }
     }
 
     hk_clip &c_;
     std::vector<std::vector<int>> nb_;
-    std::vector<char> nb_ready_;
-    std::vector<int> in_frontier_, taken_;
-    int stamp_ = 0;
+    std::unique_ptr<std::atomic<uint8_t>[]> nb_state_;
+    std::vector<char> done_;
+    std::vector<int> batch_pos_;
+    std::vector<int> batch_, todo_;
+    std::vector<SeedResult> results_;
+    std::atomic<size_t> next_{0};
+    std::atomic<int> finished_{0};
+    std::atomic<unsigned> generation_{0};
+    std::atomic<bool> quit_{false};
+    int nthreads_ = 1;
     bool has_vmax_ = false;
-    double v_max_ = 0;
-    std::vector<int> cand_, order_;
-    std::vector<double> vel_;
+    double v_max_ = 0, maxd_ = 0, e0_ = 0;
+    Rot rot_{0, 1};
 };
 
 void find_global_params(hk_clip &c, const std::vector<Arc> &arcs) {
@@ -821,12 +1017,20 @@ extern "C" int hk_clip_get_tag_state(const hk_clip *c, unsigned char *alive,
 extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_build_initial_arcs: null");
     std::vector<Arc> arcs;
+    const bool stats = getenv("HK_STEP3_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a,
+                 std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     {   // trial pass: a few confident arcs to estimate gravity
         hk::ArcBuilder b(*c);
         const int rc = b.construct(5, arcs);
         if (rc != HK_OK) return rc;
         hk::find_global_params(*c, arcs);
     }
+    const auto t1 = now();
     arcs.clear();
     {
         hk::ArcBuilder b(*c);
@@ -834,6 +1038,9 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
         if (rc != HK_OK) return rc;
         hk::find_global_params(*c, arcs);
     }
+    if (stats)
+        fprintf(stderr, "step3: trial pass %.1f ms, full pass %.1f ms\n",
+                ms(t0, t1), ms(t1, now()));
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;
     });
