@@ -6,6 +6,7 @@ needs "the next frames as BGR uint8 on the device".  A source exposes
 
     fps, width, height, frame_count_estimate
     read(max_frames) -> uint8 tensor [T][H][W][3] on the device, T == 0 at end
+    seek(frame)      -> optional; needed only for time-segmented multi-GPU runs
 
 ``open_source(path)`` resolves, in order: a source registered for that path
 (``register_source``; how tests, benchmarks and host decoders hand frames in),
@@ -58,6 +59,9 @@ class ArraySource:
             chunk = chunk.to(self.device, non_blocking=True)
         return chunk
 
+    def seek(self, frame):
+        self._pos = int(frame)
+
     def close(self):
         self._frames = None
 
@@ -84,6 +88,9 @@ class SyntheticSource:
         out = self._renderer.render(self._pos, n)
         self._pos += n
         return out
+
+    def seek(self, frame):
+        self._pos = self._first + int(frame)
 
     def close(self):
         self._renderer = None
@@ -123,6 +130,10 @@ class OpenCVSource:
                                dtype=torch.uint8, device=self.device)
         host = torch.from_numpy(np.stack(got)).pin_memory()
         return host.to(self.device, non_blocking=True)
+
+    def seek(self, frame):
+        self._cap.set(self._cv2.CAP_PROP_POS_FRAMES, int(frame))
+        self._reads = int(frame)
 
     def close(self):
         self._cap.release()

@@ -1,0 +1,76 @@
+"""
+GPU: the time-segmented layout.  MOG started cold `warmup` frames before a
+segment is an approximation; measure how close it is, and run
+the whole scan_time_segmented() path (world size 1, gloo) against the plain
+VideoScanner.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from hawkeye_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+SPEC = dict(width=640, height=480, fps=60.0, balls=4, frames=600, ball_r=6.0,
+            sigma=3.0, drift=4.0, drift_hz=0.3, distractors=4, seed=42)
+
+
+def test_warmup_overlap_mask_and_event_agreement():
+    from hawkeye_amd import dist as hkdist
+    from hawkeye_amd.detect import BackgroundSubtractorMOG, EventDetector
+    from hawkeye_amd.frames import SyntheticSource
+    frames = synth.ClipRenderer(SPEC).render(0, SPEC['frames'])
+    w, h = SPEC['width'], SPEC['height']
+    seq = BackgroundSubtractorMOG(w, h).apply_batch(frames)
+    (f0, k0, e0), (f1, k1, e1) = hkdist.segment_bounds(SPEC['frames'], 2, 200)
+    assert (f0, k0, e0, f1, k1, e1) == (0, 0, 300, 100, 300, 600)
+    seg = BackgroundSubtractorMOG(w, h).apply_batch(frames[f1:e1])[k1 - f1:]
+    agree = (seg == seq[k1:e1]).float().mean().item()
+    print('mask agreement after a 200-frame warm-up: {:.6f}'.format(agree))
+    assert agree >= 0.999                   # north_star's mask criterion
+
+    det = EventDetector(w, h)
+    whole = hkdist.detect_segment(SyntheticSource(SPEC), det, 0, 0, 600)
+    det.close()
+    parts = []
+    for first, keep, end in ((f0, k0, e0), (f1, k1, e1)):
+        det = EventDetector(w, h)
+        parts += hkdist.detect_segment(SyntheticSource(SPEC), det, first,
+                                       keep, end)
+        det.close()
+    assert len(parts) == len(whole) == 600
+    # rank 0's segment is the sequential run itself
+    assert all(np.array_equal(a, b) for a, b in zip(parts[:300], whole[:300]))
+    same = sum(a.shape == b.shape and np.abs(a[:, :2] - b[:, :2]).max(
+        initial=0) <= 0.5 for a, b in zip(parts[300:], whole[300:]))
+    print('frames of segment 2 with all centroids within 0.5 px:', same)
+    assert same >= 0.9 * 300
+
+
+def test_scan_time_segmented_world1_equals_videoscanner(tmp_path):
+    import torch.distributed as dist
+    from hawkeye_amd import dist as hkdist, frames
+    from hawkeye_amd.tracker import VideoScanner
+    spec = dict(SPEC, frames=200)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        notes = hkdist.scan_time_segmented(
+            lambda: frames.SyntheticSource(spec), warmup=50)
+    finally:
+        dist.destroy_process_group()
+    path = str(tmp_path / 'clip.mov')
+    frames.register_source(path, lambda: frames.SyntheticSource(spec))
+    try:
+        sc = VideoScanner(path)
+        sc.process(steps=(1, 4))
+    finally:
+        frames.unregister_source(path)
+    assert len(notes['arcs']) == len(sc.notes['arcs']) > 0
+    for a, b in zip(notes['arcs'], sc.notes['arcs']):
+        assert (a.a, a.b, a.c, a.e, a.f_peak) == (b.a, b.b, b.c, b.e, b.f_peak)
+    assert notes['camera_tilt'] == sc.notes['camera_tilt']
