@@ -18,7 +18,7 @@ Balltag/Ballarc objects of the notes dictionary is reported separately
 (`python_notes_ms`) and is not part of `value`.
 
 The JSON line also carries
-  roofline      for the dominant kernel (mog_batch4_k), measured live with
+  roofline      for the dominant kernel (mog_batch2_k), measured live with
                 events on the launch stream; algorithmic bytes = 324 B per
                 pixel per frame.  The kernel keeps each
                 pixel's mixture in registers across the frames of a launch,
@@ -167,7 +167,7 @@ def cpu_baseline(spec, frames_dev, gpu_events, sample):
 
 
 def traffic_from_profiles():
-    """Per-launch HBM bytes of mog_batch4_k from the committed PMC summary
+    """Per-launch HBM bytes of mog_batch2_k from the committed PMC summary
     (profiles/mog_traffic.json, written by tools/pmc_traffic.py), or None."""
     path = os.path.join(REPO, 'profiles', 'mog_traffic.json')
     try:
@@ -263,7 +263,7 @@ def main():
         (launch_ms * 1e-3) / 1e9
     traffic = traffic_from_profiles()
     roofline = {
-        'bound': 'hbm', 'kernel': 'mog_batch4_k',
+        'bound': 'hbm', 'kernel': 'mog_batch2_k',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'traffic': None if traffic is None else traffic.get('bytes_per_launch'),

@@ -233,19 +233,45 @@ inline void cpu_relax() {
 // The reference walks the seed tags (top of the frame first) one at a time.
 // A seed changes shared state in exactly one of two ways: it fails, and only
 // marks itself done, or -- rarely -- it yields an arc and marks the arc's
-// members done.  So seeds are evaluated in batches, in parallel, each under
-// the assumption that every earlier seed of its batch fails; the results are
-// then committed in order, and the first accepted arc of a batch discards the
-// later (now possibly stale) results of that batch, which are re-run.  The
-// outcome is exactly the sequential one.
+// members done.  So seeds are evaluated speculatively, in parallel, each
+// under the assumption that every earlier seed that has not been committed
+// yet fails.  One thread commits the results in queue order; a result that
+// was computed before some later-accepted arc touched the frames it looked
+// at is stale and is computed again at commit time, when everything before
+// it is final.  The outcome is exactly the sequential one.
+//
+// There is no barrier: workers run up to `window_` seeds ahead of the commit
+// position through a ring of result slots.
 class ArcBuilder {
 public:
     explicit ArcBuilder(hk_clip &c)
-        : c_(c), nb_(c.n), nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
-          done_(c.n, 0), batch_pos_(c.n, -1) {
-        for (int i = 0; i < c.n; ++i) nb_state_[i].store(0);
+        : c_(c), n_(c.n), queue_((size_t)c.n), qpos_((size_t)c.n),
+          nb_ptr_((size_t)c.n, nullptr), nb_len_((size_t)c.n, 0),
+          nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
+          done_(new std::atomic<uint8_t>[c.n ? c.n : 1]) {
+        std::iota(queue_.begin(), queue_.end(), 0);
+        std::stable_sort(queue_.begin(), queue_.end(),
+                         [&](int p, int q) { return c.y[p] < c.y[q]; });
+        for (int k = 0; k < n_; ++k) qpos_[(size_t)queue_[(size_t)k]] = k;
+        nthreads_ = worker_count();
+        scratch_.reset(new Scratch[(size_t)nthreads_]);
+        for (int t = 0; t < nthreads_; ++t) scratch_[t].init(c.n, c.F);
+        for (int t = 1; t < nthreads_; ++t)
+            pool_.emplace_back([this, t] { worker_loop(scratch_[t]); });
+    }
+
+    ~ArcBuilder() {
+        quit_.store(true);
+        generation_.fetch_add(1);
+        for (std::thread &t : pool_) t.join();
+    }
+
+    // One pass over all seeds with the clip's current gravity estimate;
+    // stops after `maxcount` arcs if maxcount > 0.
+    int construct(int maxcount, std::vector<Arc> &out) {
+        hk_clip &c = c_;
         has_vmax_ = c.has_g;
-        if (has_vmax_) v_max_ = std::sqrt(2 * c.g * c.H);
+        v_max_ = has_vmax_ ? std::sqrt(2 * c.g * c.H) : 0.0;
         maxd_ = c.p.max_distance_pixels;
         rot_ = rotation(c);
         if (c.has_g) {
@@ -254,121 +280,209 @@ public:
             const double cm_per_px = c.p.default_frame_height_cm / c.H;
             e0_ = 0.5 * G_CM / (cm_per_px * (c.fps * c.fps));
         }
-    }
+        for (int i = 0; i < n_; ++i) {
+            nb_state_[i].store(0, std::memory_order_relaxed);
+            done_[i].store(0, std::memory_order_relaxed);
+        }
+        for (int t = 0; t < nthreads_; ++t) scratch_[t].pool_reset();
 
-    int construct(int maxcount, std::vector<Arc> &out) {
-        hk_clip &c = c_;
-        std::vector<int> queue(c.n);
-        std::iota(queue.begin(), queue.end(), 0);
-        std::stable_sort(queue.begin(), queue.end(),
-                         [&](int p, int q) { return c.y[p] < c.y[q]; });
-
-        const int nthreads = worker_count();
-        nthreads_ = nthreads;
         // the trial pass stops after a handful of arcs: keep its speculation
         // shallow so that little work is thrown away
-        const size_t batch_max = maxcount > 0
-                                     ? (size_t)nthreads
-                                     : (size_t)std::max(8, 16 * nthreads);
-        std::vector<Scratch> scratch((size_t)nthreads);
-        for (Scratch &s : scratch) s.init(c.n, c.F);
-        results_.assign(batch_max, SeedResult());
+        int per_thread = 16;
+        if (const char *e = getenv("HK_STEP3_WINDOW")) per_thread = atoi(e);
+        size_t want = maxcount > 0 ? (size_t)nthreads_
+                                   : (size_t)std::max(8, per_thread * nthreads_);
+        if (nthreads_ == 1) want = 1;
+        window_ = 1;
+        while (window_ < want) window_ <<= 1;
+        slots_.reset(new Slot[window_]);
+        accepted_ranges_.clear();
+        accepted_.store(0);
+        next_.store(0);
+        commit_pos_.store(0);
+        stop_.store(false);
+        stat_stale_ = stat_helped_ = 0;
 
-        // persistent workers, released phase by phase through `generation_`
-        generation_.store(0);
-        quit_.store(false);
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t)
-            pool.emplace_back([this, &scratch, t] { worker_loop(scratch[t]); });
+        active_.store(nthreads_ - 1);
+        generation_.fetch_add(1);               // release the workers
 
-        const int reach = c.p.max_frame_gap_in_arc + 1;
+        Scratch &mine = scratch_[0];
+        const size_t Q = (size_t)n_;
         int rc = HK_OK;
-        size_t q = 0;
         int since_progress = 0;
-        bool full = false;
-        std::vector<char> stale;
-        while (q < queue.size() && !full && rc == HK_OK) {
-            // next batch: seeds not yet done, in queue order
-            batch_.clear();
-            while (q < queue.size() && batch_.size() < batch_max) {
-                const int t1 = queue[q++];
-                if (!done_[t1]) batch_.push_back(t1);
-            }
-            if (batch_.empty()) break;
-            for (size_t k = 0; k < batch_.size(); ++k)
-                batch_pos_[batch_[k]] = (int)k;
-            todo_.resize(batch_.size());
-            std::iota(todo_.begin(), todo_.end(), 0);
-            stale.assign(batch_.size(), 0);
-            run_phase(scratch[0]);
-
-            // commit in order; an accepted arc makes stale every later result
-            // that looked at frames the arc's members live in
-            size_t k = 0;
-            while (k < batch_.size() && !full && rc == HK_OK) {
-                for (; k < batch_.size(); ++k) {
-                    const int t1 = batch_[k];
-                    if (done_[t1]) continue;    // joined an arc meanwhile
-                    if (stale[k]) break;
-                    SeedResult &r = results_[k];
-                    if (r.made) {
-                        int lo = c.frame[r.arc.tags.front()], hi = lo;
-                        for (int j : r.arc.tags) {
-                            done_[j] = 1;
-                            lo = std::min(lo, c.frame[j]);
-                            hi = std::max(hi, c.frame[j]);
-                        }
-                        out.push_back(std::move(r.arc));
-                        if (maxcount > 0 && (int)out.size() >= maxcount) {
-                            full = true;
-                            break;
-                        }
-                        for (size_t m = k + 1; m < batch_.size(); ++m)
-                            if (results_[m].lo - reach <= hi &&
-                                results_[m].hi + reach >= lo)
-                                stale[m] = 1;
-                    }
-                    done_[t1] = 1;
-                    if (++since_progress >= 256) {
-                        since_progress = 0;
-                        if ((rc = report_progress(c)) != HK_OK) break;
-                    }
+        for (size_t k = 0; k < Q; ++k) {
+            const int t1 = queue_[k];
+            Slot &slot = slots_[k & (window_ - 1)];
+            if (done_[t1].load(std::memory_order_relaxed)) {
+                // joined an arc meanwhile; whoever claimed k saw that too,
+                // or will; wait for the slot so that it can be recycled
+                wait_slot(slot, k, mine);
+            } else {
+                wait_slot(slot, k, mine);
+                SeedResult &r = slot.res;
+                bool stale = slot.skipped;
+                for (size_t a = slot.epoch;
+                     !stale && a < accepted_ranges_.size(); ++a)
+                    stale = r.lo - reach() <= accepted_ranges_[a].second &&
+                            r.hi + reach() >= accepted_ranges_[a].first;
+                if (stale) {
+                    ++stat_stale_;
+                    run_seed(t1, (int)k, mine, r);
                 }
-                if (full || rc != HK_OK || k >= batch_.size()) break;
-                // recompute the stale remainder (still "predecessors fail")
-                todo_.clear();
-                for (size_t m = k; m < batch_.size(); ++m)
-                    if (stale[m] && !done_[batch_[m]]) todo_.push_back((int)m);
-                std::fill(stale.begin(), stale.end(), 0);
-                run_phase(scratch[0]);
+                if (r.made) {
+                    int lo = c.frame[r.arc.tags.front()], hi = lo;
+                    for (int j : r.arc.tags) {
+                        done_[j].store(1, std::memory_order_relaxed);
+                        lo = std::min(lo, c.frame[j]);
+                        hi = std::max(hi, c.frame[j]);
+                    }
+                    accepted_ranges_.emplace_back(lo, hi);
+                    accepted_.store(accepted_ranges_.size(),
+                                    std::memory_order_release);
+                    out.push_back(std::move(r.arc));
+                    r.made = false;
+                }
+                done_[t1].store(1, std::memory_order_relaxed);
+                if (++since_progress >= 256) {
+                    since_progress = 0;
+                    rc = report_progress(c);
+                }
             }
-            for (int t1 : batch_) batch_pos_[t1] = -1;
+            slot.state.store(0, std::memory_order_relaxed);
+            commit_pos_.store(k + 1, std::memory_order_release);
+            if (rc != HK_OK ||
+                (maxcount > 0 && (int)out.size() >= maxcount))
+                break;
         }
-
-        quit_.store(true);
-        generation_.fetch_add(1);
-        for (std::thread &t : pool) t.join();
+        stop_.store(true, std::memory_order_release);
+        while (active_.load(std::memory_order_acquire) > 0) cpu_relax();
         return rc;
     }
 
+    long stat_stale_ = 0, stat_helped_ = 0;
+
 private:
-    struct Scratch {
+    // neighbour lists live in per-thread chunked pools (no malloc per tag)
+    struct alignas(128) Scratch {   // own cache lines: no false sharing
         std::vector<int> in_frontier, taken, members, frontier, cand, order;
         std::vector<double> vel;
         int stamp = 0;
+        std::vector<std::unique_ptr<int[]>> chunks;
+        size_t chunk_used = 0, chunk_index = 0;
+        static constexpr size_t CHUNK = 1 << 16;
         void init(int n, int F) {
             in_frontier.assign((size_t)n, 0);
             taken.assign((size_t)(F > 0 ? F : 1), 0);
         }
+        void pool_reset() {
+            chunk_index = 0;
+            chunk_used = 0;
+        }
+        int *pool_alloc(size_t len) {
+            if (len > CHUNK) {      // never for real inputs; keep it correct
+                chunks.insert(chunks.begin() + (long)chunk_index,
+                              std::unique_ptr<int[]>(new int[len]));
+                return chunks[chunk_index++].get();
+            }
+            if (chunks.size() <= chunk_index || chunk_used + len > CHUNK) {
+                if (chunks.size() > chunk_index && chunk_used > 0)
+                    ++chunk_index;
+                if (chunks.size() <= chunk_index)
+                    chunks.emplace_back(new int[CHUNK]);
+                chunk_used = 0;
+            }
+            int *p = chunks[chunk_index].get() + chunk_used;
+            chunk_used += len;
+            return p;
+        }
     };
-    struct alignas(64) SeedResult {     // one cache line each: no false sharing
+    struct SeedResult {
         bool made = false;
         int lo = 0, hi = 0;     // frames of every tag the run put on a trial
         Arc arc;
     };
+    struct alignas(128) Slot {
+        std::atomic<int> state{0};      // 0 empty, 1 result ready
+        bool skipped = false;           // the seed was already done
+        size_t epoch = 0;               // arcs accepted when the run started
+        SeedResult res;
+    };
+    struct Span {
+        const int *p;
+        int len;
+        const int *begin() const { return p; }
+        const int *end() const { return p + len; }
+    };
+
+    int reach() const { return c_.p.max_frame_gap_in_arc + 1; }
 
     bool is_done(int j, int pos) const {
-        return done_[j] || (unsigned)batch_pos_[j] < (unsigned)pos;
+        return qpos_[(size_t)j] < pos ||
+               done_[j].load(std::memory_order_relaxed);
+    }
+
+    // Claims the next queue position if it lies inside the window and runs
+    // it.  Returns false if there was nothing to claim.
+    bool run_next(Scratch &s) {
+        size_t p = next_.load(std::memory_order_relaxed);
+        for (;;) {
+            if (p >= (size_t)n_ ||
+                p >= commit_pos_.load(std::memory_order_acquire) + window_)
+                return false;
+            if (next_.compare_exchange_weak(p, p + 1,
+                                            std::memory_order_relaxed))
+                break;
+        }
+        Slot &slot = slots_[p & (window_ - 1)];
+        const int t1 = queue_[p];
+        if (done_[t1].load(std::memory_order_relaxed)) {
+            slot.skipped = true;
+        } else {
+            slot.skipped = false;
+            slot.epoch = accepted_.load(std::memory_order_acquire);
+            run_seed(t1, (int)p, s, slot.res);
+        }
+        slot.state.store(1, std::memory_order_release);
+        return true;
+    }
+
+    // Committer: until slot k is ready, lend a hand.
+    void wait_slot(Slot &slot, size_t k, Scratch &mine) {
+        (void)k;
+        while (slot.state.load(std::memory_order_acquire) != 1) {
+            if (run_next(mine)) ++stat_helped_;
+            else cpu_relax();
+        }
+    }
+
+    void worker_loop(Scratch &s) {
+        unsigned seen = 0;
+        for (;;) {
+            unsigned g;
+            int spins = 0;
+            while ((g = generation_.load(std::memory_order_acquire)) == seen) {
+                if (++spins > 4000) {
+                    std::this_thread::yield();
+                    spins = 0;
+                } else {
+                    cpu_relax();
+                }
+            }
+            seen = g;
+            if (quit_.load()) return;
+            int idle = 0;
+            while (!stop_.load(std::memory_order_acquire)) {
+                if (run_next(s)) {
+                    idle = 0;
+                } else if (++idle > 2000) {
+                    std::this_thread::yield();
+                    idle = 0;
+                } else {
+                    cpu_relax();
+                }
+            }
+            active_.fetch_sub(1, std::memory_order_release);
+        }
     }
 
     // Neighbours of tag i: every tag within max_frame_gap_in_arc + 1 frames,
@@ -376,15 +490,22 @@ private:
     // capped at v_max once g is known (reference tracker.py:654-696).  Built
     // on first use by whichever thread needs it; the reference builds all of
     // them up front, which yields the same lists.
-    const std::vector<int> &neighbors(int i, Scratch &s) {
+    Span neighbors(int i, Scratch &s) {
         uint8_t st = nb_state_[i].load(std::memory_order_acquire);
-        if (st == 2) return nb_[i];
-        uint8_t expected = 0;
-        if (!nb_state_[i].compare_exchange_strong(expected, 1)) {
-            while (nb_state_[i].load(std::memory_order_acquire) != 2)
-                cpu_relax();
-            return nb_[i];
+        if (st != 2) {
+            uint8_t expected = 0;
+            if (nb_state_[i].compare_exchange_strong(expected, 1)) {
+                build_neighbors(i, s);
+                nb_state_[i].store(2, std::memory_order_release);
+            } else {
+                while (nb_state_[i].load(std::memory_order_acquire) != 2)
+                    cpu_relax();
+            }
         }
+        return Span{nb_ptr_[(size_t)i], nb_len_[(size_t)i]};
+    }
+
+    void build_neighbors(int i, Scratch &s) {
         const hk_clip &c = c_;
         const int f = c.frame[i];
         const int gap = c.p.max_frame_gap_in_arc;
@@ -395,24 +516,27 @@ private:
         for (int j = c.start[lo]; j < c.start[hi]; ++j) {
             if (c.frame[j] == f) continue;
             const double dx = c.x[j] - c.x[i], dy = c.y[j] - c.y[i];
+            const double v = std::sqrt(dx * dx + dy * dy) /
+                             std::abs(c.frame[j] - f);
+            // the speed cap does not depend on the order: apply it before
+            // the sort (same list as sorting first and filtering after)
+            if (has_vmax_ && !(v <= v_max_)) continue;
             s.cand.push_back(j);
-            s.vel.push_back(std::sqrt(dx * dx + dy * dy) /
-                            std::abs(c.frame[j] - f));
+            s.vel.push_back(v);
         }
-        s.order.resize(s.cand.size());
+        const size_t m = s.cand.size();
+        s.order.resize(m);
         std::iota(s.order.begin(), s.order.end(), 0);
         std::stable_sort(s.order.begin(), s.order.end(), [&](int p, int q) {
             return s.vel[p] < s.vel[q];
         });
-        std::vector<int> &out = nb_[i];
-        out.reserve(s.order.size());
-        for (int k : s.order)
-            if (!has_vmax_ || s.vel[k] <= v_max_) out.push_back(s.cand[k]);
-        nb_state_[i].store(2, std::memory_order_release);
-        return out;
+        int *out = m ? s.pool_alloc(m) : nullptr;
+        for (size_t k = 0; k < m; ++k) out[k] = s.cand[(size_t)s.order[k]];
+        nb_ptr_[(size_t)i] = out;
+        nb_len_[(size_t)i] = (int)m;
     }
 
-    void add_to_frontier(const std::vector<int> &src, int pos, Scratch &s) {
+    void add_to_frontier(Span src, int pos, Scratch &s) {
         for (int j : src) {
             if (is_done(j, pos) || s.taken[c_.frame[j]] == s.stamp ||
                 s.in_frontier[j] == s.stamp)
@@ -433,7 +557,7 @@ private:
             ~Publish() { r.lo = lo; r.hi = hi; }
         } publish{res, lo, hi};
         auto unit = [](int) { return 1.0; };
-        const std::vector<int> &nb1 = neighbors(t1, s);
+        const Span nb1 = neighbors(t1, s);
         for (int t2 : nb1) {
             if (is_done(t2, pos)) continue;
             ++s.stamp;
@@ -516,59 +640,24 @@ private:
         }
     }
 
-    // Runs the seeds listed in todo_ (positions in batch_) on all threads.
-    void drain(Scratch &s) {
-        for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= todo_.size()) break;
-            const int k = todo_[i];
-            run_seed(batch_[(size_t)k], k, s, results_[(size_t)k]);
-        }
-        finished_.fetch_add(1, std::memory_order_release);
-    }
-
-    void run_phase(Scratch &mine) {
-        if (todo_.empty()) return;
-        next_.store(0);
-        finished_.store(0);
-        const bool threaded = nthreads_ > 1 && todo_.size() > 1;
-        if (threaded) generation_.fetch_add(1);     // release the workers
-        drain(mine);
-        if (threaded)
-            while (finished_.load(std::memory_order_acquire) < nthreads_)
-                cpu_relax();
-    }
-
-    void worker_loop(Scratch &s) {
-        unsigned seen = 0;
-        for (;;) {
-            unsigned g;
-            int spins = 0;
-            while ((g = generation_.load(std::memory_order_acquire)) == seen) {
-                if (++spins > 4000) {
-                    std::this_thread::yield();
-                    spins = 0;
-                } else {
-                    cpu_relax();
-                }
-            }
-            seen = g;
-            if (quit_.load()) return;
-            drain(s);
-        }
-    }
-
     hk_clip &c_;
-    std::vector<std::vector<int>> nb_;
+    const int n_;
+    std::vector<int> queue_, qpos_;     // seeds top of the frame first
+    std::vector<const int *> nb_ptr_;
+    std::vector<int> nb_len_;
     std::unique_ptr<std::atomic<uint8_t>[]> nb_state_;
-    std::vector<char> done_;
-    std::vector<int> batch_pos_;
-    std::vector<int> batch_, todo_;
-    std::vector<SeedResult> results_;
-    std::atomic<size_t> next_{0};
-    std::atomic<int> finished_{0};
+    std::unique_ptr<std::atomic<uint8_t>[]> done_;
+    std::unique_ptr<Scratch[]> scratch_;
+    std::unique_ptr<Slot[]> slots_;
+    size_t window_ = 1;
+    std::vector<std::pair<int, int>> accepted_ranges_;   // committer only
+    std::vector<std::thread> pool_;
+    alignas(128) std::atomic<size_t> next_{0};
+    alignas(128) std::atomic<size_t> commit_pos_{0};
+    alignas(128) std::atomic<size_t> accepted_{0};
+    alignas(128) std::atomic<int> active_{0};
     std::atomic<unsigned> generation_{0};
-    std::atomic<bool> quit_{false};
+    std::atomic<bool> quit_{false}, stop_{false};
     int nthreads_ = 1;
     bool has_vmax_ = false;
     double v_max_ = 0, maxd_ = 0, e0_ = 0;
@@ -1024,23 +1113,23 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    {   // trial pass: a few confident arcs to estimate gravity
-        hk::ArcBuilder b(*c);
-        const int rc = b.construct(5, arcs);
-        if (rc != HK_OK) return rc;
-        hk::find_global_params(*c, arcs);
-    }
-    const auto t1 = now();
-    arcs.clear();
     {
         hk::ArcBuilder b(*c);
-        const int rc = b.construct(0, arcs);
+        // trial pass: a few confident arcs to estimate gravity
+        int rc = b.construct(5, arcs);
         if (rc != HK_OK) return rc;
         hk::find_global_params(*c, arcs);
+        const auto t1 = now();
+        arcs.clear();
+        rc = b.construct(0, arcs);
+        if (rc != HK_OK) return rc;
+        hk::find_global_params(*c, arcs);
+        if (stats)
+            fprintf(stderr,
+                    "step3: trial pass %.1f ms, full pass %.1f ms (%ld stale "
+                    "results recomputed, committer ran %ld seeds)\n",
+                    ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_helped_);
     }
-    if (stats)
-        fprintf(stderr, "step3: trial pass %.1f ms, full pass %.1f ms\n",
-                ms(t0, t1), ms(t1, now()));
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;
     });

@@ -387,10 +387,11 @@ struct Center {
 };
 
 // SimpleBlobDetector::detect()'s loop over thresholds, given that every
-// threshold sees the same centres `cur` (binary input).
-void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
-                     const hk_blob_params &p, std::vector<float> &out) {
-    std::vector<std::vector<Center>> groups;
+// threshold sees the same centres `cur` (binary input).  Literal replay;
+// returns the groups in creation order.
+void replay_groups(const std::vector<Center> &cur, int n_thresholds,
+                   const hk_blob_params &p,
+                   std::vector<std::vector<Center>> &groups) {
     const double min_dist = p.minDistBetweenBlobs;
     for (int pass = 0; pass < n_thresholds; ++pass) {
         const size_t existing = groups.size();
@@ -420,21 +421,74 @@ void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
         }
         for (auto &g : fresh) groups.push_back(std::move(g));
     }
-    for (const auto &g : groups) {
-        if ((int)g.size() < p.minRepeatability) continue;
-        double sx = 0, sy = 0, normalizer = 0;
-        for (const Center &c : g) {
-            sx += 1.0 * c.x;
-            sy += 1.0 * c.y;
-            normalizer += 1.0;
-        }
-        const double inv = 1. / normalizer;
-        sx *= inv;
-        sy *= inv;
-        out.push_back((float)sx);
-        out.push_back((float)sy);
-        out.push_back((float)(g[g.size() / 2].radius) * 2.0f);
+}
+
+// Keypoint of a group: location = sum of the members' centres (sequential
+// double adds) times 1/count, cast to float; size = twice the middle radius.
+void emit_group(const Center *g, size_t n, std::vector<float> &out) {
+    double sx = 0, sy = 0, normalizer = 0;
+    for (size_t i = 0; i < n; ++i) {
+        sx += 1.0 * g[i].x;
+        sy += 1.0 * g[i].y;
+        normalizer += 1.0;
     }
+    const double inv = 1. / normalizer;
+    sx *= inv;
+    sy *= inv;
+    out.push_back((float)sx);
+    out.push_back((float)sy);
+    out.push_back((float)(g[n / 2].radius) * 2.0f);
+}
+
+// The grouping loop without the 17-fold repetition.  A centre that no other
+// centre can ever be matched with (farther than minDistBetweenBlobs and than
+// both radii from every other centre; every group's middle element is a copy
+// of some centre) ends as a group of n_thresholds copies of itself, created
+// in the first pass at its own position in the group list.  Only the
+// remaining centres go through the literal replay, among themselves; groups
+// the replay creates after the first pass come last, as in the full loop.
+void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
+                     const hk_blob_params &p, std::vector<float> &out) {
+    const size_t n = cur.size();
+    if (n == 0 || n_thresholds <= 0) return;
+    const double min_dist = p.minDistBetweenBlobs;
+    std::vector<char> linked(n, 0);
+    bool any = false;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j) {
+            const double ddx = cur[i].x - cur[j].x, ddy = cur[i].y - cur[j].y;
+            const double dist = std::sqrt(ddx * ddx + ddy * ddy);
+            if (!(dist >= min_dist && dist >= cur[i].radius &&
+                  dist >= cur[j].radius)) {
+                linked[i] = linked[j] = 1;
+                any = true;
+            }
+        }
+    std::vector<std::vector<Center>> groups;
+    if (any) {
+        std::vector<Center> sub;
+        for (size_t i = 0; i < n; ++i)
+            if (linked[i]) sub.push_back(cur[i]);
+        replay_groups(sub, n_thresholds, p, groups);
+    }
+    const size_t first_pass = any ? (size_t)std::count(linked.begin(),
+                                                       linked.end(), 1)
+                                  : 0;
+    std::vector<Center> copies((size_t)n_thresholds);
+    size_t next_sub = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (linked[i]) {
+            const std::vector<Center> &g = groups[next_sub++];
+            if ((int)g.size() >= p.minRepeatability)
+                emit_group(g.data(), g.size(), out);
+        } else if (n_thresholds >= p.minRepeatability) {
+            std::fill(copies.begin(), copies.end(), cur[i]);
+            emit_group(copies.data(), copies.size(), out);
+        }
+    }
+    for (size_t k = first_pass; k < groups.size(); ++k)
+        if ((int)groups[k].size() >= p.minRepeatability)
+            emit_group(groups[k].data(), groups[k].size(), out);
 }
 
 }  // namespace

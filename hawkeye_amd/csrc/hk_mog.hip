@@ -150,71 +150,79 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
 }
 
 // ---------------------------------------------------------------------------
-// Fast path: contiguous frames, N % 4 == 0.  Each thread owns 4 consecutive
-// pixels: one 12-byte load and one 4-byte store per frame, float4 plane
+// Fast path: contiguous frames, N % 2 == 0.  Each lane owns 2 consecutive
+// pixels: three 2-byte loads and one 2-byte store per frame, float2 plane
 // accesses once per launch.
+//
+// The kernel is bound by VALU issue, not by HBM (the model never leaves the
+// registers during a launch), so what matters is waves per SIMD: with several
+// waves resident, one wave's scalar/branch instructions and divide/sqrt
+// latencies hide behind another's arithmetic.  WAVES = 4 caps the kernel at
+// 128 VGPRs (a few rarely-live values spill to scratch): best for long
+// batches.  WAVES = 2 (no spills) is best when a launch is a single frame and
+// the 320 B/pixel of model traffic dominate.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mog_batch4_k(
+template <int WAVES>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     float *__restrict__ planes, long n_pixels, const uint8_t *__restrict__ bgr,
     long bgr_frame_stride, uint8_t *__restrict__ mask, long mask_frame_stride,
     int nframes, int frames_before, const float *__restrict__ alpha_table,
     const MogConst c) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;    // group of 4
-    const long i0 = g * 4;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;    // pair
+    const long i0 = g * 2;
     if (i0 >= n_pixels) return;
 
-    Mix px[4];
+    Mix px[2];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float4 v = *reinterpret_cast<const float4 *>(
+            const float2 v = *reinterpret_cast<const float2 *>(
                 planes + (long)(q * K + k) * n_pixels + i0);
             px[0].f[q][k] = v.x;
             px[1].f[q][k] = v.y;
-            px[2].f[q][k] = v.z;
-            px[3].f[q][k] = v.w;
         }
     }
 
     const uint8_t *src = bgr + i0 * 3;
     uint8_t *dst = mask + i0;
-    uint3 cur = *reinterpret_cast<const uint3 *>(src);
+    const unsigned short *s16 = reinterpret_cast<const unsigned short *>(src);
+    unsigned c0 = s16[0], c1 = s16[1], c2 = s16[2];
     for (int t = 0; t < nframes; ++t) {
-        uint3 nxt = cur;
-        if (t + 1 < nframes)
-            nxt = *reinterpret_cast<const uint3 *>(
+        unsigned n0 = c0, n1 = c1, n2 = c2;
+        if (t + 1 < nframes) {          // next frame's bytes, ahead of use
+            const unsigned short *nx = reinterpret_cast<const unsigned short *>(
                 src + (long)(t + 1) * bgr_frame_stride);
+            n0 = nx[0];
+            n1 = nx[1];
+            n2 = nx[2];
+        }
         int n = frames_before + t + 1;
         n = n < HISTORY ? n : HISTORY;
         const float alpha = alpha_table[n - 1];
 
-        // bytes b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-        const unsigned a = cur.x, b = cur.y, d = cur.z;
+        // bytes b0 g0 | r0 b1 | g1 r1
         unsigned m;
-        m = mog_step(px[0], (float)(a & 255u), (float)((a >> 8) & 255u),
-                     (float)((a >> 16) & 255u), alpha, c);
-        m |= mog_step(px[1], (float)(a >> 24), (float)(b & 255u),
-                      (float)((b >> 8) & 255u), alpha, c) << 8;
-        m |= mog_step(px[2], (float)((b >> 16) & 255u), (float)(b >> 24),
-                      (float)(d & 255u), alpha, c) << 16;
-        m |= mog_step(px[3], (float)((d >> 8) & 255u),
-                      (float)((d >> 16) & 255u), (float)(d >> 24), alpha, c)
-             << 24;
-        *reinterpret_cast<unsigned *>(dst + (long)t * mask_frame_stride) = m;
-        cur = nxt;
+        m = mog_step(px[0], (float)(c0 & 255u), (float)(c0 >> 8),
+                     (float)(c1 & 255u), alpha, c);
+        m |= mog_step(px[1], (float)(c1 >> 8), (float)(c2 & 255u),
+                      (float)(c2 >> 8), alpha, c) << 8;
+        *reinterpret_cast<unsigned short *>(dst + (long)t * mask_frame_stride) =
+            (unsigned short)m;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
     }
 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            float4 v;
+            float2 v;
             v.x = px[0].f[q][k];
             v.y = px[1].f[q][k];
-            v.z = px[2].f[q][k];
-            v.w = px[3].f[q][k];
-            *reinterpret_cast<float4 *>(planes + (long)(q * K + k) * n_pixels +
+            *reinterpret_cast<float2 *>(planes + (long)(q * K + k) * n_pixels +
                                         i0) = v;
         }
     }
@@ -360,19 +368,28 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
     const hipStream_t s = (hipStream_t)stream;
     const long N = m->n_pixels;
     const bool fast =
-        bgr_pitch == 3L * m->width && mask_pitch == m->width && N % 4 == 0 &&
-        ((uintptr_t)bgr_dev & 3) == 0 && ((uintptr_t)mask_dev & 3) == 0 &&
+        bgr_pitch == 3L * m->width && mask_pitch == m->width && N % 2 == 0 &&
+        ((uintptr_t)bgr_dev & 1) == 0 && ((uintptr_t)mask_dev & 1) == 0 &&
         (nframes == 1 ||
-         (bgr_frame_stride % 4 == 0 && mask_frame_stride % 4 == 0));
+         (bgr_frame_stride % 2 == 0 && mask_frame_stride % 2 == 0));
     if (fast) {
-        const long groups = N / 4;
-        const unsigned blocks = (unsigned)((groups + 255) / 256);
-        hipLaunchKernelGGL(mog_batch4_k, dim3(blocks), dim3(256), 0, s,
-                           m->planes, N, (const uint8_t *)bgr_dev,
-                           bgr_frame_stride, (uint8_t *)mask_dev,
-                           mask_frame_stride, nframes, m->nframes,
-                           m->alpha_table, m->c);
-        HK_LAUNCH_CHECK("mog_batch4_k");
+        const long pairs = N / 2;
+        const unsigned blocks = (unsigned)((pairs + 255) / 256);
+        // short launches stream the model (HBM-bound), long ones are
+        // arithmetic-bound: see mog_batch2_k
+        if (nframes <= 4)
+            hipLaunchKernelGGL(mog_batch2_k<2>, dim3(blocks), dim3(256), 0, s,
+                               m->planes, N, (const uint8_t *)bgr_dev,
+                               bgr_frame_stride, (uint8_t *)mask_dev,
+                               mask_frame_stride, nframes, m->nframes,
+                               m->alpha_table, m->c);
+        else
+            hipLaunchKernelGGL(mog_batch2_k<4>, dim3(blocks), dim3(256), 0, s,
+                               m->planes, N, (const uint8_t *)bgr_dev,
+                               bgr_frame_stride, (uint8_t *)mask_dev,
+                               mask_frame_stride, nframes, m->nframes,
+                               m->alpha_table, m->c);
+        HK_LAUNCH_CHECK("mog_batch2_k");
     } else {
         const unsigned blocks = (unsigned)((N + 255) / 256);
         hipLaunchKernelGGL(mog_batch1_k, dim3(blocks), dim3(256), 0, s,

@@ -149,13 +149,15 @@ class SimpleBlobDetector:
             masks = masks.contiguous()
         return masks
 
-    def enqueue(self, masks):
-        """Start detection on up to max_frames masks; returns immediately.
-        The caller must keep `masks` alive until finish()."""
+    def enqueue(self, masks, stream=None):
+        """Start detection on up to max_frames masks (on `stream`, default
+        the current one); returns immediately.  The caller must keep `masks`
+        alive until finish()."""
         masks = self._check_masks(masks)
+        sp = _stream_ptr(self.device) if stream is None else stream.cuda_stream
         nat.check(nat.lib.hk_blob_enqueue(
             self._h, masks.data_ptr(), masks.stride(0), masks.stride(1),
-            masks.shape[0], _stream_ptr(self.device)))
+            masks.shape[0], sp))
         self._pending = masks.shape[0]
         self._keep = masks
 
@@ -203,6 +205,10 @@ class EventDetector:
     sets alternate, so the host-side grouping of chunk i overlaps the GPU work
     of chunk i+1); ``flush()`` returns the last chunk's.  Results come back in
     frame order: a list with one float32 [n][3] array (x, y, size) per frame.
+
+    MOG runs on the caller's current stream; the blob kernels of a chunk run
+    on a second stream behind an event, so the (latency-bound) border tracing
+    of chunk i shares the GPU with the (arithmetic-bound) MOG of chunk i+1.
     """
 
     def __init__(self, width, height, blob_params=None, chunk=128, device=0):
@@ -218,6 +224,8 @@ class EventDetector:
                       for _ in range(2)]
         self._cur = 0
         self._pending = [False, False]
+        self._side = torch.cuda.Stream(device=self.device)
+        self._mog_done = [torch.cuda.Event() for _ in range(2)]
 
     def submit(self, frames):
         t = frames.shape[0]
@@ -227,7 +235,10 @@ class EventDetector:
         p = self._cur
         masks = self.masks[p][:t]
         self.mog.apply_batch(frames, out=masks)
-        self.blob[p].enqueue(masks)
+        main = torch.cuda.current_stream(self.device)
+        self._mog_done[p].record(main)
+        self._side.wait_event(self._mog_done[p])
+        self.blob[p].enqueue(masks, stream=self._side)
         self._pending[p] = True
         self._cur = 1 - p
         return self._collect(1 - p)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of tools/profile.sh into the committed summaries
 under profiles/: the kernel stats table and mog_traffic.json (HBM bytes per
-launch of mog_batch4_k = 2 x FETCH_SIZE + WRITE_SIZE, in KiB units, the 2x
+launch of mog_batch2_k = 2 x FETCH_SIZE + WRITE_SIZE, in KiB units, the 2x
 being the gfx950 wide-read correction of MI355X_MICROARCH.md, §HBM)."""
 import csv
 import json
@@ -17,7 +17,7 @@ os.makedirs('profiles', exist_ok=True)
 def counter(name, counter_name, frames=128):
     path = os.path.join(src, name, 'pmc_counter_collection.csv')
     rows = [r for r in csv.DictReader(open(path))
-            if 'mog_batch4_k' in r['Kernel_Name'] and
+            if 'mog_batch2_k' in r['Kernel_Name'] and
             r['Counter_Name'] == counter_name]
     vals = [float(r['Counter_Value']) for r in rows]
     return vals
@@ -30,7 +30,7 @@ write_kib = sum(write) / len(write)
 px = 1920 * 1080
 per_launch = int(round((2 * fetch_kib + write_kib) * 1024))
 out = {
-    'kernel': 'mog_batch4_k', 'frames_per_launch': 128,
+    'kernel': 'mog_batch2_k', 'frames_per_launch': 128,
     'launches_sampled': len(fetch),
     'FETCH_SIZE_KiB': fetch_kib, 'WRITE_SIZE_KiB': write_kib,
     'bytes_per_launch': per_launch,
