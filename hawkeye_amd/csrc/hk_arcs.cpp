@@ -139,13 +139,19 @@ bool acceleration_ok(const hk_clip &clip, double e) {
 
 namespace {
 
+void solve_fit(Arc &arc, const Moments &m, const Rot &rot);
+
 // Weighted parabola fit of one arc over `tags` (reference tracker.py:713-798).
 // Leaves the arc untouched if the normal equations are near singular.
 template <class WeightOf>
 void fit_one(const hk_clip &c, Arc &arc, const std::vector<int> &tags,
              const Rot &rot, WeightOf weight_of) {
     if (tags.size() < 3) return;
-    const Moments m = moments(c, arc, tags, weight_of);
+    solve_fit(arc, moments(c, arc, tags, weight_of), rot);
+}
+
+// The normal equations of fit_one, given the moment sums.
+void solve_fit(Arc &arc, const Moments &m, const Rot &rot) {
     const double T0 = m.T0, T1 = m.T1, T2 = m.T2, T3 = m.T3, T4 = m.T4;
     const double det2 = T0 * T2 - T1 * T1;
     const double det3 = 2 * T1 * T2 * T3 + T0 * T2 * T4 - T0 * (T3 * T3) -
@@ -235,10 +241,11 @@ inline void cpu_relax() {
 // marks itself done, or -- rarely -- it yields an arc and marks the arc's
 // members done.  So seeds are evaluated speculatively, in parallel, each
 // under the assumption that every earlier seed that has not been committed
-// yet fails.  One thread commits the results in queue order; a result that
-// was computed before some later-accepted arc touched the frames it looked
-// at is stale and is computed again at commit time, when everything before
-// it is final.  The outcome is exactly the sequential one.
+// yet fails.  One thread commits the results in queue order.  A run notes
+// every tag whose "not done yet" status it relied on; if an arc accepted
+// after the run started took one of those tags, the result is stale and is
+// computed again at commit time, when everything before it is final.  The
+// outcome is exactly the sequential one.
 //
 // There is no barrier: workers run up to `window_` seeds ahead of the commit
 // position through a ring of result slots.
@@ -248,7 +255,8 @@ public:
         : c_(c), n_(c.n), queue_((size_t)c.n), qpos_((size_t)c.n),
           nb_ptr_((size_t)c.n, nullptr), nb_len_((size_t)c.n, 0),
           nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
-          done_(new std::atomic<uint8_t>[c.n ? c.n : 1]) {
+          done_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
+          done_at_((size_t)c.n, -1) {
         std::iota(queue_.begin(), queue_.end(), 0);
         std::stable_sort(queue_.begin(), queue_.end(),
                          [&](int p, int q) { return c.y[p] < c.y[q]; });
@@ -273,6 +281,8 @@ public:
         has_vmax_ = c.has_g;
         v_max_ = has_vmax_ ? std::sqrt(2 * c.g * c.H) : 0.0;
         maxd_ = c.p.max_distance_pixels;
+        maxd_sq_lo_ = maxd_ * maxd_ * (1 - 1e-12);
+        maxd_sq_hi_ = maxd_ * maxd_ * (1 + 1e-12);
         rot_ = rotation(c);
         if (c.has_g) {
             e0_ = 0.5 * c.g;
@@ -288,7 +298,7 @@ public:
 
         // the trial pass stops after a handful of arcs: keep its speculation
         // shallow so that little work is thrown away
-        int per_thread = 16;
+        int per_thread = 256;
         if (const char *e = getenv("HK_STEP3_WINDOW")) per_thread = atoi(e);
         size_t want = maxcount > 0 ? (size_t)nthreads_
                                    : (size_t)std::max(8, per_thread * nthreads_);
@@ -296,12 +306,14 @@ public:
         window_ = 1;
         while (window_ < want) window_ <<= 1;
         slots_.reset(new Slot[window_]);
-        accepted_ranges_.clear();
+        std::fill(done_at_.begin(), done_at_.end(), -1);
+        n_accepted_ = 0;
         accepted_.store(0);
         next_.store(0);
         commit_pos_.store(0);
         stop_.store(false);
         stat_stale_ = stat_helped_ = 0;
+        stat_stale_ms_ = 0;
 
         active_.store(nthreads_ - 1);
         generation_.fetch_add(1);               // release the workers
@@ -321,24 +333,26 @@ public:
                 wait_slot(slot, k, mine);
                 SeedResult &r = slot.res;
                 bool stale = slot.skipped;
-                for (size_t a = slot.epoch;
-                     !stale && a < accepted_ranges_.size(); ++a)
-                    stale = r.lo - reach() <= accepted_ranges_[a].second &&
-                            r.hi + reach() >= accepted_ranges_[a].first;
+                if (!stale && slot.epoch < n_accepted_)
+                    for (int j : r.consulted)
+                        if (done_at_[(size_t)j] >= (long)slot.epoch) {
+                            stale = true;
+                            break;
+                        }
                 if (stale) {
                     ++stat_stale_;
+                    const auto ts = std::chrono::steady_clock::now();
                     run_seed(t1, (int)k, mine, r);
+                    stat_stale_ms_ += std::chrono::duration<double, std::milli>(
+                        std::chrono::steady_clock::now() - ts).count();
                 }
                 if (r.made) {
-                    int lo = c.frame[r.arc.tags.front()], hi = lo;
                     for (int j : r.arc.tags) {
                         done_[j].store(1, std::memory_order_relaxed);
-                        lo = std::min(lo, c.frame[j]);
-                        hi = std::max(hi, c.frame[j]);
+                        done_at_[(size_t)j] = (long)n_accepted_;
                     }
-                    accepted_ranges_.emplace_back(lo, hi);
-                    accepted_.store(accepted_ranges_.size(),
-                                    std::memory_order_release);
+                    ++n_accepted_;
+                    accepted_.store(n_accepted_, std::memory_order_release);
                     out.push_back(std::move(r.arc));
                     r.made = false;
                 }
@@ -360,18 +374,21 @@ public:
     }
 
     long stat_stale_ = 0, stat_helped_ = 0;
+    double stat_stale_ms_ = 0;
 
 private:
     // neighbour lists live in per-thread chunked pools (no malloc per tag)
     struct alignas(128) Scratch {   // own cache lines: no false sharing
         std::vector<int> in_frontier, taken, members, frontier, cand, order;
-        std::vector<double> vel;
-        int stamp = 0;
+        std::vector<double> vel, mf, mx, my, fq;
+        std::vector<int> seen;          // per run: tag already in `consulted`
+        int stamp = 0, run_stamp = 0;
         std::vector<std::unique_ptr<int[]>> chunks;
         size_t chunk_used = 0, chunk_index = 0;
         static constexpr size_t CHUNK = 1 << 16;
         void init(int n, int F) {
             in_frontier.assign((size_t)n, 0);
+            seen.assign((size_t)n, 0);
             taken.assign((size_t)(F > 0 ? F : 1), 0);
         }
         void pool_reset() {
@@ -398,7 +415,8 @@ private:
     };
     struct SeedResult {
         bool made = false;
-        int lo = 0, hi = 0;     // frames of every tag the run put on a trial
+        // tags the run found "not done" and may have used for that reason
+        std::vector<int> consulted;
         Arc arc;
     };
     struct alignas(128) Slot {
@@ -413,8 +431,6 @@ private:
         const int *begin() const { return p; }
         const int *end() const { return p + len; }
     };
-
-    int reach() const { return c_.p.max_frame_gap_in_arc + 1; }
 
     bool is_done(int j, int pos) const {
         return qpos_[(size_t)j] < pos ||
@@ -536,10 +552,18 @@ private:
         nb_len_[(size_t)i] = (int)m;
     }
 
-    void add_to_frontier(Span src, int pos, Scratch &s) {
+    static void consult(int j, Scratch &s, SeedResult &res) {
+        if (s.seen[j] != s.run_stamp) {
+            s.seen[j] = s.run_stamp;
+            res.consulted.push_back(j);
+        }
+    }
+
+    void add_to_frontier(Span src, int pos, Scratch &s, SeedResult &res) {
         for (int j : src) {
-            if (is_done(j, pos) || s.taken[c_.frame[j]] == s.stamp ||
-                s.in_frontier[j] == s.stamp)
+            if (is_done(j, pos)) continue;
+            consult(j, s, res);
+            if (s.taken[c_.frame[j]] == s.stamp || s.in_frontier[j] == s.stamp)
                 continue;
             s.in_frontier[j] = s.stamp;
             s.frontier.push_back(j);
@@ -548,32 +572,83 @@ private:
 
     // One seed: try its neighbours in order until one pair grows into an
     // acceptable arc (reference tracker.py:521-625).
+    // Squared distance of a tag at (frame f, x, y) to the arc: the operations
+    // of arc_tag_distance, minus the final square root.
+    double dist_sq(const Arc &arc, double f, double x, double y) const {
+        const double t = f - arc.f_peak;
+        const double xj = arc.a + arc.b * t;
+        const double yj = arc.c + arc.e * t * t;
+        const double px = xj * rot_.c + yj * rot_.s;
+        const double py = yj * rot_.c - xj * rot_.s;
+        const double dx = px - x, dy = py - y;
+        return dx * dx + dy * dy;
+    }
+
+    // sqrt(q) > maxd_, deciding without the root unless q is within rounding
+    // of the boundary (sqrt is monotonic and correctly rounded).
+    bool farther_than_maxd(double q) const {
+        if (q > maxd_sq_hi_) return true;
+        if (q < maxd_sq_lo_) return false;
+        return std::sqrt(q) > maxd_;
+    }
+
+    // fit_one() for unit weights over the member arrays (1.0 * v == v, so
+    // the weight factors drop out bit for bit).
+    void fit_members(Arc &arc, const Scratch &s) const {
+        const size_t n = s.members.size();
+        if (n < 3) return;
+        Moments m;
+        const double fp = arc.f_peak;
+        for (size_t i = 0; i < n; ++i) {
+            const double t = s.mf[i] - fp;
+            const double x = s.mx[i], y = s.my[i];
+            const double t2 = t * t;
+            m.T0 += 1.0;
+            m.T1 += t;
+            m.T2 += t2;
+            m.T3 += t2 * t;
+            m.T4 += t2 * t2;
+            m.X1 += x;
+            m.TX += t * x;
+            m.T2X += t2 * x;
+            m.Y1 += y;
+            m.TY += t * y;
+            m.T2Y += t2 * y;
+        }
+        solve_fit(arc, m, rot_);
+    }
+
+    // One seed: try its neighbours in order until one pair grows into an
+    // acceptable arc (reference tracker.py:521-625).
     void run_seed(int t1, int pos, Scratch &s, SeedResult &res) {
         const hk_clip &c = c_;
         res.made = false;
-        int lo = c.frame[t1], hi = lo;
-        struct Publish {        // touched frame range, written once on exit
-            SeedResult &r; int &lo, &hi;
-            ~Publish() { r.lo = lo; r.hi = hi; }
-        } publish{res, lo, hi};
-        auto unit = [](int) { return 1.0; };
+        res.consulted.clear();
+        ++s.run_stamp;
         const Span nb1 = neighbors(t1, s);
         for (int t2 : nb1) {
             if (is_done(t2, pos)) continue;
+            consult(t2, s, res);
             ++s.stamp;
             Arc arc;
             const int f1 = c.frame[t1], f2 = c.frame[t2];
+            // members in ascending tag order, with their coordinates alongside
             std::vector<int> &members = s.members;
             members.clear();
-            members.push_back(std::min(t1, t2));
-            members.push_back(std::max(t1, t2));
+            s.mf.clear();
+            s.mx.clear();
+            s.my.clear();
+            for (int j : {std::min(t1, t2), std::max(t1, t2)}) {
+                members.push_back(j);
+                s.mf.push_back((double)c.frame[j]);
+                s.mx.push_back(c.x[j]);
+                s.my.push_back(c.y[j]);
+            }
             s.taken[f1] = s.stamp;
             s.taken[f2] = s.stamp;
-            lo = std::min(lo, f2);
-            hi = std::max(hi, f2);
             s.frontier.clear();
-            add_to_frontier(nb1, pos, s);
-            add_to_frontier(neighbors(t2, s), pos, s);
+            add_to_frontier(nb1, pos, s, res);
+            add_to_frontier(neighbors(t2, s), pos, s, res);
 
             arc.e = e0_;
             arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
@@ -585,23 +660,55 @@ private:
 
             bool bad = false;
             while (!s.frontier.empty()) {
+                // nearest frontier tag: smallest distance, lowest index among
+                // equals.  Compared on squared distances; the roots are only
+                // taken among those within rounding of the smallest.
+                const size_t nf = s.frontier.size();
+                s.fq.resize(nf);
+                double q_min = 0;
+                for (size_t i = 0; i < nf; ++i) {
+                    const int j = s.frontier[i];
+                    const double q =
+                        dist_sq(arc, (double)c.frame[j], c.x[j], c.y[j]);
+                    s.fq[i] = q;
+                    if (i == 0 || q < q_min) q_min = q;
+                }
                 int best = -1;
                 double best_d = 0;
-                for (int j : s.frontier) {
-                    const double d = arc_tag_distance(c, arc, rot_, j);
-                    if (best < 0 || d < best_d || (d == best_d && j < best)) {
-                        best = j;
-                        best_d = d;
+                if (q_min == q_min) {
+                    const double q_tie = q_min * (1 + 1e-14);
+                    for (size_t i = 0; i < nf; ++i) {
+                        if (!(s.fq[i] <= q_tie)) continue;
+                        const int j = s.frontier[i];
+                        const double d = std::sqrt(s.fq[i]);
+                        if (best < 0 || d < best_d ||
+                            (d == best_d && j < best)) {
+                            best = j;
+                            best_d = d;
+                        }
+                    }
+                }
+                if (best < 0) {         // NaN distances: the literal scan
+                    for (size_t i = 0; i < nf; ++i) {
+                        const int j = s.frontier[i];
+                        const double d = std::sqrt(s.fq[i]);
+                        if (best < 0 || d < best_d ||
+                            (d == best_d && j < best)) {
+                            best = j;
+                            best_d = d;
+                        }
                     }
                 }
                 if (best_d > maxd_) break;
-                members.insert(
-                    std::upper_bound(members.begin(), members.end(), best),
-                    best);
+                const size_t at = (size_t)(
+                    std::upper_bound(members.begin(), members.end(), best) -
+                    members.begin());
+                members.insert(members.begin() + (long)at, best);
+                s.mf.insert(s.mf.begin() + (long)at, (double)c.frame[best]);
+                s.mx.insert(s.mx.begin() + (long)at, c.x[best]);
+                s.my.insert(s.my.begin() + (long)at, c.y[best]);
                 s.taken[c.frame[best]] = s.stamp;
-                lo = std::min(lo, c.frame[best]);
-                hi = std::max(hi, c.frame[best]);
-                add_to_frontier(neighbors(best, s), pos, s);
+                add_to_frontier(neighbors(best, s), pos, s, res);
                 s.frontier.erase(
                     std::remove_if(s.frontier.begin(), s.frontier.end(),
                                    [&](int j) {
@@ -610,7 +717,7 @@ private:
                     s.frontier.end());
                 bool refit = false;
                 if ((int)members.size() > c.p.min_tags_to_curve_fit) {
-                    fit_one(c, arc, members, rot_, unit);
+                    fit_members(arc, s);
                     refit = true;
                 }
                 if (std::isnan(arc.e) || arc.e <= 0) {
@@ -618,8 +725,10 @@ private:
                     break;
                 }
                 if (refit) {
-                    for (int j : members)
-                        if (arc_tag_distance(c, arc, rot_, j) > maxd_) {
+                    const size_t nm = members.size();
+                    for (size_t i = 0; i < nm; ++i)
+                        if (farther_than_maxd(
+                                dist_sq(arc, s.mf[i], s.mx[i], s.my[i]))) {
                             bad = true;
                             break;
                         }
@@ -629,7 +738,9 @@ private:
                 // best_d <= maxd
                 if (bad) break;
             }
-            if (!bad) {
+            // eval_arc() fails with fewer than min_tags_per_arc members
+            // whatever else holds: skip the call
+            if (!bad && (int)members.size() >= c.p.min_tags_per_arc) {
                 arc.tags = members;
                 if (eval_arc_host(c, arc, rot_, false, true) == 0) {
                     res.arc = std::move(arc);
@@ -650,7 +761,8 @@ private:
     std::unique_ptr<Scratch[]> scratch_;
     std::unique_ptr<Slot[]> slots_;
     size_t window_ = 1;
-    std::vector<std::pair<int, int>> accepted_ranges_;   // committer only
+    std::vector<long> done_at_;     // committer only: accept number of the
+    size_t n_accepted_ = 0;         // arc that took the tag, or -1
     std::vector<std::thread> pool_;
     alignas(128) std::atomic<size_t> next_{0};
     alignas(128) std::atomic<size_t> commit_pos_{0};
@@ -660,7 +772,7 @@ private:
     std::atomic<bool> quit_{false}, stop_{false};
     int nthreads_ = 1;
     bool has_vmax_ = false;
-    double v_max_ = 0, maxd_ = 0, e0_ = 0;
+    double v_max_ = 0, maxd_ = 0, maxd_sq_lo_ = 0, maxd_sq_hi_ = 0, e0_ = 0;
     Rot rot_{0, 1};
 };
 
@@ -1127,8 +1239,9 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
         if (stats)
             fprintf(stderr,
                     "step3: trial pass %.1f ms, full pass %.1f ms (%ld stale "
-                    "results recomputed, committer ran %ld seeds)\n",
-                    ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_helped_);
+                    "results recomputed in %.1f ms, committer ran %ld seeds)\n",
+                    ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_stale_ms_,
+                    b.stat_helped_);
     }
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;

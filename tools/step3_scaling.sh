@@ -1,6 +1,7 @@
 #!/bin/bash
-# Thread / batch scaling of the step-3 builder on the box's host cores.
+# Thread / window scaling of the step-3 builder on the box's host cores.
 export PYTHONPATH=$PWD
-for t in 1 4 8 16; do for b in 16 32 64; do
-  echo "T=$t B=$b"; HK_STEP3_WINDOW=$b HK_STEP3_STATS=1 HK_THREADS=$t python tools/time_step3.py tools/_events_C.npz 2>&1 | grep -E "step3:" | tail -2
+lscpu | grep -E "Thread|Core|Socket|^CPU\(s\)"
+for t in 10 12 14 16; do for b in 16 64 256; do
+  echo "T=$t W=$b"; HK_STEP3_WINDOW=$b HK_STEP3_STATS=1 HK_THREADS=$t python tools/time_step3.py tools/_events_C.npz 2>&1 | grep -E "step3:" | tail -2
 done; done
