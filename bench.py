@@ -13,9 +13,15 @@ torch.distributed.run, one rank per GPU) every rank runs one such clip (own
 seed) -- the clip-sharded layout of configs[4] -- and the per-rank arc tables
 are gathered to rank 0 over RCCL; value = all frames of all ranks / max time.
 
-Timed through the C ABI (events and arcs as SoA arrays); building the Python
-Balltag/Ballarc objects of the notes dictionary is reported separately
-(`python_notes_ms`) and is not part of `value`.
+The K timed steps run the way a batch of clips runs in production
+(hawkeye_amd.batch.ClipScanner.scan_many): as a two-stage pipeline in which
+the GPU detects pass k+2 while the host cores run step 3 of pass k+1 and
+step 4 of pass k.
+Every pass does all of the work, and nothing is cached between passes.  The
+latency of one clip on its own (no overlap) is reported as `single_clip_ms`.
+
+Timed through the C ABI (events and arcs as SoA arrays), without building the
+Python Balltag/Ballarc objects of the notes dictionary.
 
 The JSON line also carries
   roofline      for the dominant kernel (mog_batch2_k), measured live with
@@ -46,89 +52,12 @@ import torch                                    # noqa: E402
 import torch.distributed as dist                # noqa: E402
 
 from hawkeye_amd import synth                   # noqa: E402
-from hawkeye_amd.arcs import Clip, scan_params  # noqa: E402
-from hawkeye_amd.detect import EventDetector    # noqa: E402
+from hawkeye_amd.batch import ClipScanner       # noqa: E402
 
 WORKLOAD = 'C_1080p60_9ball_noisy'
 CHUNK = 128
 ALGO_BYTES_PER_PIXEL_FRAME = 324       # 3 in + 1 out + 160 model rd + 160 wr
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-
-def events_to_soa(per_frame, spec):
-    """Keypoints -> the SoA arrays of notes['meas'] (same float64 expressions
-    as reference tracker.py:335-342, 413-417 with scan video == source)."""
-    counts = np.fromiter((len(k) for k in per_frame), np.int64,
-                         len(per_frame))
-    frame = np.repeat(np.arange(len(per_frame), dtype=np.int32), counts)
-    kp = (np.concatenate(per_frame) if counts.sum() else
-          np.zeros((0, 3), np.float32)).astype(np.float64)
-    h, w = spec['height'], spec['width']
-    scale = h / h
-    pad_left = (w - h * (w / h)) / 2
-    return frame, pad_left + kp[:, 0] * scale, kp[:, 1] * scale, \
-        kp[:, 2] * scale
-
-
-class Pipeline:
-    def __init__(self, spec, frames, device):
-        self.spec, self.frames, self.device = spec, frames, device
-        self.det = EventDetector(spec['width'], spec['height'], chunk=CHUNK,
-                                 device=device)
-        self.params = scan_params(spec['height'], spec['height'], spec['fps'])
-        self.mog_ms = []            # per-launch durations of the MOG kernel
-        self.mog_frames = []
-        self.time_mog = False
-        self.stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
-
-    def detect(self):
-        det, frames = self.det, self.frames
-        det.mog.reset()
-        out = []
-        pairs = []
-        orig = det.mog.apply_batch
-        if self.time_mog:
-            def timed(fr, out=None):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = orig(fr, out=out)
-                e1.record()
-                pairs.append((e0, e1, fr.shape[0]))
-                return r
-            det.mog.apply_batch = timed
-        try:
-            for s in range(0, frames.shape[0], CHUNK):
-                out.extend(det.submit(frames[s:s + CHUNK]))
-            out.extend(det.flush())
-        finally:
-            det.mog.apply_batch = orig
-        for e0, e1, n in pairs:
-            self.mog_ms.append(e0.elapsed_time(e1))
-            self.mog_frames.append(n)
-        return out
-
-    def step(self):
-        spec = self.spec
-        t0 = time.perf_counter()
-        per_frame = self.detect()
-        frame, x, y, r = events_to_soa(per_frame, spec)
-        t1 = time.perf_counter()
-        clip = Clip(spec['width'], spec['height'], spec['fps'],
-                    self.frames.shape[0], frame, x, y, r, params=self.params,
-                    device=self.device)
-        clip.build_initial_arcs()
-        t2 = time.perf_counter()
-        clip.em_optimize()
-        params, ids, members = clip.arcs()
-        alive, final = clip.tag_state()
-        tilt = clip.state()['camera_tilt']
-        clip.close()
-        t3 = time.perf_counter()
-        self.stage_s['detect'] += t1 - t0
-        self.stage_s['step3'] += t2 - t1
-        self.stage_s['step4'] += t3 - t2
-        return per_frame, params, int(alive.sum()), tilt
 
 
 def cpu_baseline(spec, frames_dev, gpu_events, sample):
@@ -208,25 +137,43 @@ def main():
     renderer = synth.ClipRenderer(spec, device=local)
     frames = renderer.render(0, spec['frames'])
     torch.cuda.synchronize()
-    pipe = Pipeline(spec, frames, local)
+    scanner = ClipScanner(spec['width'], spec['height'], spec['fps'],
+                          device=local, chunk=CHUNK)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up, and the latency of one clip scanned on its own (no overlap
+    # between the detection and the arc stages)
     for _ in range(args.warmup):
-        result = pipe.step()
-    pipe.stage_s = {k: 0.0 for k in pipe.stage_s}
-    pipe.time_mog = True
+        result = scanner.scan(frames)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    result = scanner.scan(frames)
+    single_ms = (time.perf_counter() - t0) * 1e3
+    single_stages = result.stage_seconds
+
+    # K steps = K passes of the whole hot path over the clip, as a two-stage
+    # pipeline: detection of pass k+1 on the GPU while the host builds the
+    # arcs of pass k (ClipScanner.scan_many)
+    scanner.detector.mog_timing = []
+    stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = pipe.step()
+    for result in scanner.scan_many(frames for _ in range(args.steps)):
+        for k in stage_s:
+            stage_s[k] += result.stage_seconds[k]
     barrier()
     elapsed = time.perf_counter() - t0
+    mog_ms = [e0.elapsed_time(e1) for e0, e1, _ in
+              scanner.detector.mog_timing]
+    mog_frames = [n for _, _, n in scanner.detector.mog_timing]
+    scanner.detector.mog_timing = None
 
-    per_frame, arc_params, tags_left, tilt = result
+    per_frame, arc_params = result.events, result.arc_params
+    tags_left, tilt = int(result.alive.sum()), result.camera_tilt
     # collect every rank's arc table on rank 0 (RCCL), and the slowest time
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -253,8 +200,8 @@ def main():
     total_frames = spec['frames'] * args.steps * world
     value = total_frames / elapsed
     px = spec['width'] * spec['height']
-    mog_ms = np.array(pipe.mog_ms)
-    mog_fr = np.array(pipe.mog_frames)
+    mog_ms = np.array(mog_ms)
+    mog_fr = np.array(mog_frames)
     full = mog_fr == CHUNK                  # launches of a whole chunk
     launch_ms = float(mog_ms[full].mean()) if full.any() else \
         float(mog_ms.mean())
@@ -293,8 +240,14 @@ def main():
                    'clips': world, 'sharding': 'one clip per GPU, arc tables '
                    'gathered to rank 0 over RCCL' if world > 1 else 'single GPU',
                    'detect_chunk_frames': CHUNK},
+        'pipeline': 'three stages side by side: detection of pass k+2 '
+                    '(GPU), step 3 of pass k+1 (host cores), step 4 of pass '
+                    'k; every pass does all the work',
         'stage_ms_per_step': {k: round(v / args.steps * 1e3, 3)
-                              for k, v in pipe.stage_s.items()},
+                              for k, v in stage_s.items()},
+        'single_clip_ms': None if single_ms is None else round(single_ms, 3),
+        'single_clip_stage_ms': None if single_ms is None else {
+            k: round(v * 1e3, 3) for k, v in single_stages.items()},
         'result': {'events': int(sum(len(k) for k in per_frame)),
                    'arcs': total_arcs, 'tags_on_arcs': tags_left,
                    'camera_tilt_rad': tilt},

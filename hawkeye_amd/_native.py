@@ -52,6 +52,8 @@ def _sig(name, argtypes, restype=C.c_int):
 _sig('hk_last_error', [], C.c_char_p)
 _sig('hk_version', [])
 _sig('hk_device_count', [])
+_sig('hk_release_cached_memory', [])
+_sig('hk_set_host_threads', [C.c_int])
 
 _sig('hk_mog_create', [C.c_int, C.c_int, C.c_int, c_void_pp])
 _sig('hk_mog_destroy', [C.c_void_p])

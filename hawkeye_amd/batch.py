@@ -1,0 +1,264 @@
+"""
+Array-level driver of steps 2-4 for one clip or a batch of clips.
+
+``VideoScanner`` (hawkeye_amd/tracker.py) is the reference's object API: it
+builds ``Balltag`` / ``Ballarc`` objects and the ``notes`` dictionary.  This
+module is what sits underneath when many clips are analysed (BASELINE.json
+configs[4]) or when only the arrays are wanted: frames in, events and arcs
+out as NumPy arrays, through the same C ABI.
+
+    scanner = ClipScanner(width, height, fps, device=0)
+    result = scanner.scan(frames)                  # one clip
+    for result in scanner.scan_many(clips): ...    # pipelined batch
+
+Step 2 is GPU work (MOG + blob kernels) with a thin host loop; steps 3-4 are
+host work (multi-threaded step 3, merge / prune control flow) around small
+EM kernels.  ``scan_many`` therefore runs them as a two-stage pipeline: a
+worker thread detects clip i+1 on its own HIP stream while the calling thread
+builds the arcs of clip i (EM kernels on a second, high-priority stream).
+Results are the same as scanning the clips one by one, in the same order.
+"""
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .arcs import Clip, scan_params
+from .detect import EventDetector, hawkeye_blob_params
+
+
+class ClipResult:
+    """Events and arcs of one clip.
+
+    events         list, one float32 [n][3] array (x, y, size) per frame:
+                   the keypoints of step 2 in scan-video coordinates
+    frame, x, y, radius   the same events as notes['meas'] holds them, SoA
+    arc_params     float64 [A][5] = a, b, c, e, f_peak (sorted by f_peak)
+    arc_ids, arc_members   id_ per arc; member event indices per arc
+    alive, final_arc       per event: kept by clean_notes / index of tag.arc
+    camera_tilt, g_px_per_frame_sq, cm_per_pixel   notes scalars
+    """
+    __slots__ = ('events', 'frame', 'x', 'y', 'radius', 'frame_count',
+                 'arc_params', 'arc_ids', 'arc_members', 'alive', 'final_arc',
+                 'camera_tilt', 'g_px_per_frame_sq', 'cm_per_pixel',
+                 'stage_seconds')
+
+
+def events_to_soa(per_frame, frame_width, frame_height, scan_width,
+                  scan_height):
+    """Keypoints -> the SoA arrays of notes['meas']: the float64 expressions
+    of reference tracker.py:335-342, 413-417 (the blob *diameter* goes into
+    Balltag.radius, as the reference does)."""
+    counts = np.fromiter((len(k) for k in per_frame), np.int64,
+                         len(per_frame))
+    frame = np.repeat(np.arange(len(per_frame), dtype=np.int32), counts)
+    kp = (np.concatenate(per_frame) if counts.sum() else
+          np.zeros((0, 3), np.float32)).astype(np.float64)
+    scale = frame_height / scan_height
+    crop_w = frame_height * (scan_width / scan_height)
+    pad_left = (frame_width - crop_w) / 2
+    return frame, pad_left + kp[:, 0] * scale, kp[:, 1] * scale, \
+        kp[:, 2] * scale
+
+
+class ClipScanner:
+    def __init__(self, width, height, fps, device=0, chunk=128,
+                 frame_size=None, params=None):
+        """width x height: the scanned frames.  frame_size = (W, H) of the
+        source video if a down-scaled scan video is analysed (reference
+        tracker.py:310-342), else None."""
+        self.width, self.height, self.fps = int(width), int(height), \
+            float(fps)
+        self.frame_width, self.frame_height = (
+            (self.width, self.height) if frame_size is None else
+            (int(frame_size[0]), int(frame_size[1])))
+        self.device = int(device)
+        self.chunk = int(chunk)
+        self.params = params if params is not None else scan_params(
+            self.frame_height, self.height, self.fps)
+        self._det = EventDetector(self.width, self.height,
+                                  blob_params=hawkeye_blob_params(self.height),
+                                  chunk=self.chunk, device=self.device)
+        dev = torch.device('cuda', self.device)
+        self._detect_stream = torch.cuda.Stream(device=dev)
+        self._em_stream = torch.cuda.Stream(device=dev, priority=-1)
+
+    @property
+    def detector(self):
+        return self._det
+
+    def close(self):
+        det, self._det = getattr(self, '_det', None), None
+        if det is not None:
+            det.close()
+
+    __del__ = close
+
+    # -- step 2 ------------------------------------------------------------
+
+    def detect(self, frames):
+        """frames: uint8 [T][H][W][3] BGR on the device, or a frame source
+        (hawkeye_amd.frames) with read().  Returns the per-frame keypoints."""
+        det = self._det
+        out = []
+        with torch.cuda.stream(self._detect_stream):
+            det.mog.reset()
+            chunks = (self._from_source(frames) if hasattr(frames, 'read')
+                      else (frames[s:s + self.chunk]
+                            for s in range(0, frames.shape[0], self.chunk)))
+            for chunk in chunks:
+                out.extend(det.submit(chunk))
+            out.extend(det.flush())
+        return out
+
+    def _from_source(self, src):
+        while True:
+            chunk = src.read(self.chunk)
+            if chunk.shape[0] == 0:
+                return
+            yield chunk
+
+    # -- steps 3-4 ---------------------------------------------------------
+
+    def build_arcs(self, per_frame, result=None):
+        """Step 3 on the keypoints of one clip.  Returns (result, clip); the
+        open native clip goes to refine_arcs()."""
+        res = result if result is not None else ClipResult()
+        t0 = time.perf_counter()
+        res.events = per_frame
+        res.frame_count = len(per_frame)
+        res.frame, res.x, res.y, res.radius = events_to_soa(
+            per_frame, self.frame_width, self.frame_height, self.width,
+            self.height)
+        clip = Clip(self.frame_width, self.frame_height, self.fps,
+                    res.frame_count, res.frame, res.x, res.y, res.radius,
+                    params=self.params, device=self.device,
+                    stream=self._em_stream.cuda_stream)
+        try:
+            clip.build_initial_arcs()
+        except BaseException:
+            clip.close()
+            raise
+        self._stage(res, 'step3', time.perf_counter() - t0)
+        return res, clip
+
+    def refine_arcs(self, res, clip):
+        """Step 4 and the read-back of its results; closes the clip."""
+        t0 = time.perf_counter()
+        try:
+            clip.em_optimize()
+            res.arc_params, res.arc_ids, res.arc_members = clip.arcs()
+            res.alive, res.final_arc = clip.tag_state()
+            st = clip.state()
+        finally:
+            clip.close()
+        res.camera_tilt = st['camera_tilt']
+        res.g_px_per_frame_sq = st['g_px_per_frame_sq']
+        res.cm_per_pixel = st['cm_per_pixel']
+        self._stage(res, 'step4', time.perf_counter() - t0)
+        return res
+
+    @staticmethod
+    def _stage(res, name, seconds):
+        stages = getattr(res, 'stage_seconds', None) or {}
+        stages[name] = seconds
+        res.stage_seconds = stages
+
+    # -- whole clips -------------------------------------------------------
+
+    def scan(self, frames):
+        t0 = time.perf_counter()
+        per_frame = self.detect(frames)
+        res = ClipResult()
+        self._stage(res, 'detect', time.perf_counter() - t0)
+        return self.refine_arcs(*self.build_arcs(per_frame, res))
+
+    def scan_many(self, clips, host_threads=None):
+        """Generator over the results of `clips` (an iterable of frame
+        tensors / sources of this scanner's size), in order.  Three stages
+        run side by side: detection of clip i+2 (GPU, worker thread), step 3
+        of clip i+1 (host cores, worker thread) and step 4 of clip i (calling
+        thread)."""
+        detected = queue.Queue(maxsize=1)
+        built = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def put(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def get(q):
+            while not stop.is_set():
+                try:
+                    return q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            return None
+
+        def detect_stage():
+            try:
+                torch.cuda.set_device(self.device)
+                for frames in clips:
+                    if stop.is_set():
+                        return
+                    t0 = time.perf_counter()
+                    per_frame = self.detect(frames)
+                    res = ClipResult()
+                    self._stage(res, 'detect', time.perf_counter() - t0)
+                    if not put(detected, (per_frame, res)):
+                        return
+                put(detected, None)
+            except BaseException as exc:    # noqa: B902 - re-raised below
+                put(detected, exc)
+
+        def build_stage():
+            try:
+                torch.cuda.set_device(self.device)
+                while True:
+                    item = get(detected)
+                    if item is None or isinstance(item, BaseException):
+                        put(built, item)
+                        return
+                    if not put(built, self.build_arcs(*item)):
+                        item = None
+                        return
+            except BaseException as exc:    # noqa: B902 - re-raised below
+                put(built, exc)
+
+        # leave cores to the detection loop and to step 4 while step 3 runs
+        if host_threads is None:
+            cores = min(os.cpu_count() or 1,
+                        int(os.environ.get('OMP_NUM_THREADS', '16')), 16)
+            host_threads = max(1, cores - 2)
+        nat.check(nat.lib.hk_set_host_threads(int(host_threads)))
+        workers = [threading.Thread(target=detect_stage, daemon=True),
+                   threading.Thread(target=build_stage, daemon=True)]
+        for w in workers:
+            w.start()
+        try:
+            while True:
+                item = built.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield self.refine_arcs(*item)
+        finally:
+            stop.set()
+            for w in workers:
+                w.join()
+            for q in (detected, built):     # close clips nobody will refine
+                while not q.empty():
+                    item = q.get_nowait()
+                    if isinstance(item, tuple) and isinstance(item[1], Clip):
+                        item[1].close()
+            nat.check(nat.lib.hk_set_host_threads(0))

@@ -221,9 +221,13 @@ int report_progress(hk_clip &c) {
 
 // Worker threads for step 3.  The box's CPU share is what OMP_NUM_THREADS
 // says (the GPU boxes export 16); never more than 16.
+std::atomic<int> g_host_threads{0};     // hk_set_host_threads(); 0 = auto
+
 int worker_count() {
     int n = (int)std::thread::hardware_concurrency();
-    if (const char *e = getenv("HK_THREADS")) n = atoi(e);
+    const int forced = g_host_threads.load();
+    if (forced > 0) n = forced;
+    else if (const char *e = getenv("HK_THREADS")) n = atoi(e);
     else if (const char *o = getenv("OMP_NUM_THREADS")) n = std::min(n, atoi(o));
     return std::max(1, std::min(n, 16));
 }
@@ -867,11 +871,18 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
                                cache[i2].good.begin(), cache[i2].good.end(),
                                std::back_inserter(trial_tags));
                 if ((int)trial_tags.size() < c.p.min_tags_per_arc) continue;
-                Arc trial = a1;
+                Arc trial;              // copy.copy(arc1): parameters only
+                trial.a = a1.a;
+                trial.b = a1.b;
+                trial.c = a1.c;
+                trial.e = a1.e;
+                trial.f_peak = a1.f_peak;
                 fit_one(c, trial, trial_tags, rot, tw_of);
                 int poor = 0;
                 for (int t : trial_tags)
-                    if (arc_tag_distance(c, trial, rot, t) > maxd) ++poor;
+                    if (arc_tag_distance(c, trial, rot, t) > maxd &&
+                        ++poor > 2)
+                        break;
                 if (poor > 2) continue;
 
                 // merge a2 into a1
@@ -1258,43 +1269,60 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
 extern "C" int hk_clip_em_optimize(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_em_optimize: null clip");
     const hipStream_t s = (hipStream_t)stream;
-    int rc = hk::em_prepare(*c);
-    if (rc != HK_OK) return rc;
+    const bool stats = getenv("HK_STEP4_STATS") != nullptr;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rounds = 0;
+    auto timed = [&](int slot, int rc_in, auto &&fn) {
+        if (rc_in != HK_OK) return rc_in;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int r = fn();
+        ms[slot] += std::chrono::duration<double, std::milli>(
+                        std::chrono::steady_clock::now() - t0).count();
+        return r;
+    };
+    int rc = timed(0, HK_OK, [&] { return hk::em_prepare(*c, s); });
     bool again = true;
-    while (again) {
-        if ((rc = hk::em_tilt(*c, s)) != HK_OK) return rc;
-        if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+    while (again && rc == HK_OK) {
+        ++rounds;
+        rc = timed(1, rc, [&] { return hk::em_tilt(*c, s); });
+        rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
         again = false;
         for (Arc &a : c->arcs) a.done = false;
-        if ((rc = hk::merge_phase(*c, s, again)) != HK_OK) return rc;
-        if ((rc = hk::prune_phase(*c, s, again)) != HK_OK) return rc;
-        if ((rc = hk::em_estep(*c, s)) != HK_OK) return rc;
-        if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+        rc = timed(3, rc, [&] { return hk::merge_phase(*c, s, again); });
+        rc = timed(4, rc, [&] { return hk::prune_phase(*c, s, again); });
+        rc = timed(5, rc, [&] { return hk::em_estep(*c, s); });
+        rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
     }
-    if ((rc = hk::clean(*c)) != HK_OK) return rc;
-    if ((rc = hk::em_tilt(*c, s)) != HK_OK) return rc;
-    if ((rc = hk::em_fit(*c, s)) != HK_OK) return rc;
+    rc = timed(6, rc, [&] { return hk::clean(*c); });
+    rc = timed(1, rc, [&] { return hk::em_tilt(*c, s); });
+    rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
+    if (rc != HK_OK) return rc;
     hk::sort_arcs_by_peak(*c);
+    if (stats)
+        fprintf(stderr,
+                "step4: %d rounds; prepare %.2f, tilt %.2f, fit %.2f, merge "
+                "%.2f, prune %.2f, E-step %.2f, clean %.2f ms\n",
+                rounds, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);
     return HK_OK;
 }
 
 extern "C" int hk_clip_calculate_weights(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_calculate_weights: null");
-    const int rc = hk::em_prepare(*c);
+    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
     if (rc != HK_OK) return rc;
     return hk::em_estep(*c, (hipStream_t)stream);
 }
 
 extern "C" int hk_clip_fit_arcs(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_fit_arcs: null clip");
-    const int rc = hk::em_prepare(*c);
+    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
     if (rc != HK_OK) return rc;
     return hk::em_fit(*c, (hipStream_t)stream);
 }
 
 extern "C" int hk_clip_estimate_camera_tilt(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_estimate_camera_tilt: null");
-    const int rc = hk::em_prepare(*c);
+    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
     if (rc != HK_OK) return rc;
     return hk::em_tilt(*c, (hipStream_t)stream);
 }
@@ -1311,12 +1339,23 @@ extern "C" int hk_clip_member_distances(hk_clip *c, double *dist,
                                         void *stream) {
     if (!c || !dist)
         return hk::fail(HK_ERR_ARG, "hk_clip_member_distances: null");
-    int rc = hk::em_prepare(*c);
+    int rc = hk::em_prepare(*c, (hipStream_t)stream);
     if (rc != HK_OK) return rc;
     std::vector<double> d;
     std::vector<long> off;
     rc = hk::em_member_distances(*c, (hipStream_t)stream, d, off);
     if (rc != HK_OK) return rc;
     std::copy(d.begin(), d.end(), dist);
+    return HK_OK;
+}
+
+extern "C" int hk_release_cached_memory(void) {
+    hk::em_release_cached();
+    return HK_OK;
+}
+
+extern "C" int hk_set_host_threads(int n) {
+    if (n < 0) return hk::fail(HK_ERR_ARG, "hk_set_host_threads: %d", n);
+    hk::g_host_threads.store(n);
     return HK_OK;
 }

@@ -27,6 +27,7 @@ struct DeviceState {
     bool ready = false;
     int device = 0;
     int n = 0;                          // tags
+    int tag_cap = 0;                    // capacity of the tag arrays
     int *frame = nullptr;
     double *x = nullptr, *y = nullptr, *r = nullptr, *tw = nullptr;
     double *total = nullptr;            // [n] per-tag weight sums
@@ -91,8 +92,9 @@ void arc_frame_range(const hk_clip &clip, const Arc &arc, int &f_min,
 double median_tag_radius(const hk_clip &clip, const std::vector<int> &tags);
 
 // --- device side (hk_em.hip) ------------------------------------------------
-int em_prepare(hk_clip &clip);                      // upload tags once
-void em_release(hk_clip &clip);
+int em_prepare(hk_clip &clip, hipStream_t stream);  // upload tags once
+void em_release(hk_clip &clip);      // parks the workspace for the next clip
+void em_release_cached();            // frees the parked workspaces
 // E-step for every arc: raw weights, per-tag totals, normalisation; fills
 // arc.w_lo/w_hi/w_off and arc.tags (ascending).  (reference tracker.py:992-1039)
 int em_estep(hk_clip &clip, hipStream_t stream);

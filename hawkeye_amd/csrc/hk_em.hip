@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "hk_clip.h"
 
@@ -389,42 +390,16 @@ int run_moments(hk_clip &c, hipStream_t s, int what) {
 
 namespace hk {
 
-int em_prepare(hk_clip &c) {
-    DeviceState &d = c.dev;
-    if (d.ready) return HK_OK;
-    DeviceGuard guard(c.device);
-    if (!guard.ok)
-        return fail(HK_ERR_HIP, "cannot select device %d", c.device);
-    d.device = c.device;
-    d.n = c.n;
-    const size_t n = (size_t)c.n;
-    HK_HIP(dev_alloc(d.frame, n));
-    HK_HIP(dev_alloc(d.x, n));
-    HK_HIP(dev_alloc(d.y, n));
-    HK_HIP(dev_alloc(d.r, n));
-    HK_HIP(dev_alloc(d.tw, n));
-    HK_HIP(dev_alloc(d.total, n));
-    if (n) {
-        HK_HIP(hipMemcpy(d.frame, c.frame.data(), sizeof(int) * n,
-                         hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d.x, c.x.data(), sizeof(double) * n,
-                         hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d.y, c.y.data(), sizeof(double) * n,
-                         hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d.r, c.r.data(), sizeof(double) * n,
-                         hipMemcpyHostToDevice));
-        HK_HIP(hipMemcpy(d.tw, c.tw.data(), sizeof(double) * n,
-                         hipMemcpyHostToDevice));
-    }
-    d.ready = true;
-    return HK_OK;
-}
+// Device workspaces outlive the clips that use them: hipMalloc / hipFree
+// (the latter synchronises the whole device) cost more than a whole EM pass
+// on a clip, so a released workspace is parked here, per device, and the next
+// clip on that device takes it over.  hk_release_cached_memory() frees them.
+namespace {
+constexpr size_t POOL_MAX = 4;
+std::mutex g_pool_mutex;
+std::vector<DeviceState> g_pool;
 
-void em_release(hk_clip &c) {
-    DeviceState &d = c.dev;
-    if (!d.ready && !d.arc_cap && !d.weight_cap && !d.bitmap_cap &&
-        !d.list_cap)
-        return;
+void free_workspace(DeviceState &d) {
     DeviceGuard guard(d.device);
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
@@ -435,6 +410,90 @@ void em_release(hk_clip &c) {
     (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_bitmap);
     (void)hipHostFree(d.h_list); (void)hipHostFree(d.h_list_out);
     d = DeviceState();
+}
+
+int ensure_tag_capacity(DeviceState &d, int n) {
+    if (n <= d.tag_cap) return HK_OK;
+    const size_t cap = (size_t)std::max(2 * (long)n, 1L << 16);
+    (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
+    (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
+    d.frame = nullptr;
+    d.x = d.y = d.r = d.tw = d.total = nullptr;
+    d.tag_cap = 0;
+    HK_HIP(dev_alloc(d.frame, cap));
+    HK_HIP(dev_alloc(d.x, cap));
+    HK_HIP(dev_alloc(d.y, cap));
+    HK_HIP(dev_alloc(d.r, cap));
+    HK_HIP(dev_alloc(d.tw, cap));
+    HK_HIP(dev_alloc(d.total, cap));
+    d.tag_cap = (int)cap;
+    return HK_OK;
+}
+}  // namespace
+
+int em_prepare(hk_clip &c, hipStream_t s) {
+    DeviceState &d = c.dev;
+    if (d.ready) return HK_OK;
+    DeviceGuard guard(c.device);
+    if (!guard.ok)
+        return fail(HK_ERR_HIP, "cannot select device %d", c.device);
+    if (!d.tag_cap && !d.arc_cap) {         // take over a parked workspace
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == c.device) {
+                d = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                break;
+            }
+    }
+    d.device = c.device;
+    d.n = c.n;
+    const int rc = ensure_tag_capacity(d, c.n);
+    if (rc != HK_OK) return rc;
+    const size_t n = (size_t)c.n;
+    if (n) {
+        HK_HIP(hipMemcpyAsync(d.frame, c.frame.data(), sizeof(int) * n,
+                              hipMemcpyHostToDevice, s));
+        HK_HIP(hipMemcpyAsync(d.x, c.x.data(), sizeof(double) * n,
+                              hipMemcpyHostToDevice, s));
+        HK_HIP(hipMemcpyAsync(d.y, c.y.data(), sizeof(double) * n,
+                              hipMemcpyHostToDevice, s));
+        HK_HIP(hipMemcpyAsync(d.r, c.r.data(), sizeof(double) * n,
+                              hipMemcpyHostToDevice, s));
+        HK_HIP(hipMemcpyAsync(d.tw, c.tw.data(), sizeof(double) * n,
+                              hipMemcpyHostToDevice, s));
+        // the sources are pageable vectors of the clip: make sure the copies
+        // have left them before anything can change
+        HK_HIP(hipStreamSynchronize(s));
+    }
+    d.ready = true;
+    return HK_OK;
+}
+
+void em_release(hk_clip &c) {
+    DeviceState &d = c.dev;
+    if (!d.tag_cap && !d.arc_cap && !d.weight_cap && !d.bitmap_cap &&
+        !d.list_cap)
+        return;
+    d.ready = false;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool.size() < POOL_MAX) {
+            g_pool.push_back(d);
+            d = DeviceState();
+            return;
+        }
+    }
+    free_workspace(d);
+}
+
+void em_release_cached() {
+    std::vector<DeviceState> all;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        all.swap(g_pool);
+    }
+    for (DeviceState &d : all) free_workspace(d);
 }
 
 int em_estep(hk_clip &c, hipStream_t s) {

@@ -224,6 +224,9 @@ class EventDetector:
                       for _ in range(2)]
         self._cur = 0
         self._pending = [False, False]
+        # set to a list to collect (start, end, frames) event triples of the
+        # MOG launches, recorded on the stream they run on
+        self.mog_timing = None
         self._side = torch.cuda.Stream(device=self.device)
         self._mog_done = [torch.cuda.Event() for _ in range(2)]
 
@@ -234,8 +237,16 @@ class EventDetector:
                                                                    self.chunk))
         p = self._cur
         masks = self.masks[p][:t]
-        self.mog.apply_batch(frames, out=masks)
         main = torch.cuda.current_stream(self.device)
+        if self.mog_timing is None:
+            self.mog.apply_batch(frames, out=masks)
+        else:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            self.mog.apply_batch(frames, out=masks)
+            e1.record(main)
+            self.mog_timing.append((e0, e1, t))
         self._mog_done[p].record(main)
         self._side.wait_event(self._mog_done[p])
         self.blob[p].enqueue(masks, stream=self._side)

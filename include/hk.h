@@ -46,6 +46,10 @@ int hk_version(void);
 /* Number of HIP devices visible, or a negative status. */
 int hk_device_count(void);
 
+/* Destroyed clips park their device workspace (a few MB) for the next clip on
+ * the same device instead of freeing it; this frees what is parked. */
+int hk_release_cached_memory(void);
+
 /* ------------------------------------------------------------------------
  * K1  MOG background subtraction
  *     replaces cv2.bgsegm.createBackgroundSubtractorMOG()  (reference
@@ -233,8 +237,11 @@ int hk_clip_get_arcs(const hk_clip *c, double *params5, int *ids,
 int hk_clip_get_tag_state(const hk_clip *c, unsigned char *alive,
                           int *final_arc);
 
-/* Step 3 (host only). */
+/* Step 3 (host only; multi-threaded, same result for any thread count). */
 int hk_clip_build_initial_arcs(hk_clip *c);
+/* Host threads step 3 may use: 0 = automatic (the smaller of the hardware
+ * concurrency, OMP_NUM_THREADS and 16), else exactly n (at most 16). */
+int hk_set_host_threads(int n);
 /* Step 4.  Synchronises `stream` as needed. */
 int hk_clip_em_optimize(hk_clip *c, void *stream);
 

@@ -1,0 +1,112 @@
+"""
+GPU: the array-level clip driver (hawkeye_amd.batch) -- one clip, a pipelined
+batch of clips, and agreement with the object-level VideoScanner.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def small_spec(seed, frames=150, balls=3):
+    from hawkeye_amd import synth
+    spec = dict(synth.CLIPS['B_720p30_5ball'])
+    spec.update(width=320, height=240, frames=frames, seed=seed, balls=balls,
+                ball_r=4.0)
+    return spec
+
+
+def render(spec):
+    from hawkeye_amd import synth
+    return synth.ClipRenderer(spec, device=0).render(0, spec['frames'])
+
+
+def same_result(a, b):
+    assert len(a.events) == len(b.events)
+    for p, q in zip(a.events, b.events):
+        assert np.array_equal(p.view(np.uint32), q.view(np.uint32))
+    assert np.array_equal(a.arc_params, b.arc_params)
+    assert np.array_equal(a.arc_ids, b.arc_ids)
+    assert all(np.array_equal(m, n)
+               for m, n in zip(a.arc_members, b.arc_members))
+    assert np.array_equal(a.alive, b.alive)
+    assert np.array_equal(a.final_arc, b.final_arc)
+    assert a.camera_tilt == b.camera_tilt
+
+
+def test_pipelined_batch_equals_clip_by_clip():
+    from hawkeye_amd.batch import ClipScanner
+    specs = [small_spec(4100 + i, balls=3 + i % 3) for i in range(5)]
+    clips = [render(s) for s in specs]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, specs[0]['fps'], device=0, chunk=64)
+    one_by_one = [sc.scan(c) for c in clips]
+    assert any(len(r.arc_params) for r in one_by_one)
+    batched = list(sc.scan_many(iter(clips)))
+    assert len(batched) == len(clips)
+    for a, b in zip(one_by_one, batched):
+        same_result(a, b)
+    # again, to catch state leaking from one batch into the next
+    for a, b in zip(one_by_one, sc.scan_many(clips)):
+        same_result(a, b)
+    sc.close()
+
+
+def test_batch_stops_cleanly_when_the_consumer_stops():
+    from hawkeye_amd.batch import ClipScanner
+    clips = [render(small_spec(4200 + i, frames=80)) for i in range(4)]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
+    gen = sc.scan_many(clips)
+    first = next(gen)
+    gen.close()                     # abandons the remaining clips
+    again = sc.scan(clips[0])
+    same_result(first, again)
+    sc.close()
+
+
+def test_errors_in_a_stage_reach_the_caller():
+    from hawkeye_amd.batch import ClipScanner
+    good = render(small_spec(4300, frames=60))
+    bad = torch.zeros((10, 100, 100, 3), dtype=torch.uint8, device='cuda')
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
+    with pytest.raises(ValueError):
+        list(sc.scan_many([good, bad, good]))
+    same_result(sc.scan(good), sc.scan(good))
+    sc.close()
+
+
+def test_matches_videoscanner_notes():
+    """Same events and arcs as the reference-shaped VideoScanner produces."""
+    from hawkeye_amd import frames as fsrc
+    from hawkeye_amd.batch import ClipScanner
+    from hawkeye_amd.tracker import VideoScanner
+    spec = small_spec(4400, frames=200, balls=3)
+    clip = render(spec)
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, spec['fps'], device=0, chunk=64)
+    res = sc.scan(clip)
+    sc.close()
+
+    path = '/virtual/batch_vs_scanner.mov'
+    fsrc.register_source(path, lambda: fsrc.ArraySource(clip, spec['fps']))
+    try:
+        vs = VideoScanner(path)
+        vs.process(steps=(1, 4))
+    finally:
+        fsrc.unregister_source(path)
+    notes = vs.notes
+    # events of step 2 that survived clean_notes, in order
+    kept = [(t.frame, t.x, t.y, t.radius)
+            for f in range(notes['frame_count']) for t in notes['meas'][f]]
+    mine = [(int(f), x, y, r) for f, x, y, r, a in
+            zip(res.frame, res.x, res.y, res.radius, res.alive) if a]
+    assert kept == mine
+    arcs = sorted(notes['arcs'], key=lambda a: a.f_peak)
+    assert len(arcs) == len(res.arc_params)
+    for a, p in zip(arcs, res.arc_params):
+        assert (a.a, a.b, a.c, a.e, a.f_peak) == tuple(p)
+    assert notes['camera_tilt'] == res.camera_tilt
