@@ -109,7 +109,7 @@ def traffic_from_profiles():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--frames', type=int, default=None,
                     help='shorter clip (debugging only; invalidates value)')
@@ -155,9 +155,8 @@ def main():
     single_ms = (time.perf_counter() - t0) * 1e3
     single_stages = result.stage_seconds
 
-    # K steps = K passes of the whole hot path over the clip, as a two-stage
-    # pipeline: detection of pass k+1 on the GPU while the host builds the
-    # arcs of pass k (ClipScanner.scan_many)
+    # K steps = K passes of the whole hot path over the clip, pipelined the
+    # way a batch of clips is (ClipScanner.scan_many)
     scanner.detector.mog_timing = []
     stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
     barrier()

@@ -13,10 +13,11 @@ out as NumPy arrays, through the same C ABI.
 
 Step 2 is GPU work (MOG + blob kernels) with a thin host loop; steps 3-4 are
 host work (multi-threaded step 3, merge / prune control flow) around small
-EM kernels.  ``scan_many`` therefore runs them as a two-stage pipeline: a
-worker thread detects clip i+1 on its own HIP stream while the calling thread
-builds the arcs of clip i (EM kernels on a second, high-priority stream).
-Results are the same as scanning the clips one by one, in the same order.
+EM kernels.  ``scan_many`` therefore runs them as a three-stage pipeline:
+one worker thread detects clip i+2 on its own HIP stream, another runs step 3
+of clip i+1 on the host cores, and the calling thread runs step 4 of clip i
+(EM kernels on a second, high-priority stream).  Results are the same as
+scanning the clips one by one, in the same order.
 """
 import os
 import queue
