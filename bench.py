@@ -95,6 +95,33 @@ def cpu_baseline(spec, frames_dev, gpu_events, sample):
     return base, parity
 
 
+def from_host_rate(scanner, spec, frames_dev, nframes, device):
+    """The same hot path fed from page-locked host memory (what a host
+    decoder hands over): chunks cross PCIe on a copy stream while the previous
+    chunk is processed.  Reported beside `value`, never as `value`."""
+    from hawkeye_amd.frames import PinnedHostSource
+    n = min(nframes, frames_dev.shape[0])
+    host = PinnedHostSource.alloc(n, spec['height'], spec['width'])
+    host.copy_(frames_dev[:n])
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        src = PinnedHostSource(host, spec['fps'], device=device, chunk=CHUNK)
+        t0 = time.perf_counter()
+        events = scanner.detect(src)
+        dt = time.perf_counter() - t0
+        src.close()
+        best = dt if best is None else min(best, dt)
+    ref = scanner.detect(frames_dev[:n])
+    same = all(np.array_equal(a, b) for a, b in zip(events, ref))
+    gb = n * spec['height'] * spec['width'] * 3 / 1e9
+    return {'frames': n, 'detect_fps': round(n / best, 1),
+            'h2d_GBps': round(gb / best, 2),
+            'events_equal_device_resident': bool(same),
+            'note': 'step 2 only, frames read from pinned host memory '
+                    'through hawkeye_amd.frames.PinnedHostSource'}
+
+
 def traffic_from_profiles():
     """Per-launch HBM bytes of mog_batch2_k from the committed PMC summary
     (profiles/mog_traffic.json, written by tools/pmc_traffic.py), or None."""
@@ -115,6 +142,9 @@ def main():
                     help='shorter clip (debugging only; invalidates value)')
     ap.add_argument('--cpu-sample', type=int, default=96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-frames', type=int, default=512,
+                    help='frames of the PCIe-inclusive side measurement '
+                         '(0 = skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -252,6 +282,10 @@ def main():
                    'camera_tilt_rad': tilt},
         'roofline': roofline,
     }
+
+    if world == 1 and args.host_frames > 0:
+        out['pcie_inclusive'] = from_host_rate(scanner, spec, frames,
+                                               args.host_frames, local)
 
     if world == 1 and not args.no_cpu_baseline:
         sample = min(args.cpu_sample, spec['frames'])

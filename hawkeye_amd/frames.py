@@ -66,6 +66,98 @@ class ArraySource:
         self._frames = None
 
 
+class PinnedHostSource:
+    """Frames in page-locked host memory, streamed to the device ahead of use.
+
+    This is the ingest path for a host decoder (reference tracker.py:383
+    decodes with cv2.VideoCapture on the CPU): the decoder writes BGR frames
+    into a pinned buffer, and read() hands out device chunks while the next
+    chunk is already crossing PCIe on a copy stream.  Three device buffers
+    rotate, so a chunk is never overwritten while kernels enqueued on the
+    caller's stream may still read it.
+
+    ``frames``: uint8 tensor [T][H][W][3], pinned (``torch.Tensor.pin_memory``
+    or ``PinnedHostSource.alloc``); a pageable tensor / NumPy array is pinned
+    once up front (one extra host copy).
+    """
+
+    BUFFERS = 3
+
+    @staticmethod
+    def alloc(nframes, height, width):
+        """Page-locked uint8 [T][H][W][3] for a decoder to fill."""
+        return torch.empty((nframes, height, width, 3), dtype=torch.uint8,
+                           pin_memory=True)
+
+    def __init__(self, frames, fps, device=0, chunk=128):
+        self.device = torch.device('cuda', device)
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or \
+                frames.shape[3] != 3 or frames.is_cuda:
+            raise ValueError('frames must be host uint8 [T][H][W][3] (BGR)')
+        if not frames.is_pinned():
+            frames = frames.contiguous().pin_memory()
+        self._frames = frames
+        self.fps = float(fps)
+        self.frame_count_estimate = int(frames.shape[0])
+        self.height, self.width = int(frames.shape[1]), int(frames.shape[2])
+        self._chunk = int(chunk)
+        self._copy = torch.cuda.Stream(device=self.device)
+        self._buf = [torch.empty((self._chunk, self.height, self.width, 3),
+                                 dtype=torch.uint8, device=self.device)
+                     for _ in range(self.BUFFERS)]
+        self._ready = [torch.cuda.Event() for _ in range(self.BUFFERS)]
+        self._pos = 0           # next frame to hand out
+        self._k = 0             # index of the next chunk handed out
+        self._staged = None     # (chunk index, first frame, count) in flight
+
+    def _stage(self, k, first, reuse_after):
+        """Start copying frames [first, first+n) into buffer k % BUFFERS."""
+        n = min(self._chunk, self.frame_count_estimate - first)
+        if n <= 0:
+            self._staged = None
+            return
+        b = k % self.BUFFERS
+        self._copy.wait_event(reuse_after)
+        with torch.cuda.stream(self._copy):
+            self._buf[b][:n].copy_(self._frames[first:first + n],
+                                   non_blocking=True)
+            self._ready[b].record(self._copy)
+        self._staged = (k, first, n)
+
+    def read(self, max_frames):
+        if max_frames != self._chunk:
+            raise ValueError('PinnedHostSource was built for chunks of {} '
+                             'frames'.format(self._chunk))
+        cur = torch.cuda.current_stream(self.device)
+        # everything enqueued so far on the caller's stream (the kernels that
+        # read earlier chunks) must finish before a buffer is written again
+        fence = torch.cuda.Event()
+        fence.record(cur)
+        if self._staged is None or self._staged[1] != self._pos:
+            self._stage(self._k, self._pos, fence)      # first read / seek
+        if self._staged is None:
+            return torch.empty((0, self.height, self.width, 3),
+                               dtype=torch.uint8, device=self.device)
+        k, first, n = self._staged
+        b = k % self.BUFFERS
+        self._pos = first + n
+        self._k = k + 1
+        self._stage(self._k, self._pos, fence)          # prefetch the next
+        cur.wait_event(self._ready[b])
+        return self._buf[b][:n]
+
+    def seek(self, frame):
+        self._pos = int(frame)
+
+    def close(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._copy.synchronize()
+        self._frames = None
+        self._buf = []
+
+
 class SyntheticSource:
     """A clip of hawkeye_amd.synth rendered on the device chunk by chunk."""
 

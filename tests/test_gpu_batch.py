@@ -110,3 +110,32 @@ def test_matches_videoscanner_notes():
     for a, p in zip(arcs, res.arc_params):
         assert (a.a, a.b, a.c, a.e, a.f_peak) == tuple(p)
     assert notes['camera_tilt'] == res.camera_tilt
+
+
+def test_pinned_host_source_streams_the_same_frames():
+    """Frames fed from page-locked host memory (double-buffered upload on a
+    copy stream) give the events of the device-resident clip, for chunk
+    counts that do and do not divide the clip."""
+    from hawkeye_amd.batch import ClipScanner
+    from hawkeye_amd.frames import PinnedHostSource
+    spec = small_spec(4500, frames=230, balls=4)
+    clip = render(spec)
+    torch.cuda.synchronize()
+    for chunk in (32, 64, 230):
+        sc = ClipScanner(320, 240, spec['fps'], device=0, chunk=chunk)
+        want = sc.detect(clip)
+        host = PinnedHostSource.alloc(spec['frames'], 240, 320)
+        host.copy_(clip)
+        torch.cuda.synchronize()
+        src = PinnedHostSource(host, spec['fps'], device=0, chunk=chunk)
+        got = sc.detect(src)
+        src.close()
+        # a pageable NumPy clip is accepted too (pinned once up front)
+        src = PinnedHostSource(clip.cpu().numpy(), spec['fps'], device=0,
+                               chunk=chunk)
+        got2 = sc.detect(src)
+        src.close()
+        sc.close()
+        assert len(got) == len(want) == len(got2) == spec['frames']
+        for a, b, c in zip(want, got, got2):
+            assert np.array_equal(a, b) and np.array_equal(a, c)
