@@ -142,6 +142,9 @@ def main():
                     help='shorter clip (debugging only; invalidates value)')
     ap.add_argument('--cpu-sample', type=int, default=96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-threads', type=int, default=None,
+                    help='step-3 worker threads in the pipelined run '
+                         '(default: host cores - 2, at most 14)')
     ap.add_argument('--host-frames', type=int, default=512,
                     help='frames of the PCIe-inclusive side measurement '
                          '(0 = skip)')
@@ -191,7 +194,8 @@ def main():
     stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
     barrier()
     t0 = time.perf_counter()
-    for result in scanner.scan_many(frames for _ in range(args.steps)):
+    for result in scanner.scan_many((frames for _ in range(args.steps)),
+                                    host_threads=args.host_threads):
         for k in stage_s:
             stage_s[k] += result.stage_seconds[k]
     barrier()

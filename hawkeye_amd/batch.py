@@ -16,7 +16,7 @@ host work (multi-threaded step 3, merge / prune control flow) around small
 EM kernels.  ``scan_many`` therefore runs them as a three-stage pipeline:
 one worker thread detects clip i+2 on its own HIP stream, another runs step 3
 of clip i+1 on the host cores, and the calling thread runs step 4 of clip i
-(EM kernels on a second, high-priority stream).  Results are the same as
+(EM kernels on a second stream).  Results are the same as
 scanning the clips one by one, in the same order.
 """
 import os
@@ -86,7 +86,7 @@ class ClipScanner:
                                   chunk=self.chunk, device=self.device)
         dev = torch.device('cuda', self.device)
         self._detect_stream = torch.cuda.Stream(device=dev)
-        self._em_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self._em_stream = torch.cuda.Stream(device=dev)
 
     @property
     def detector(self):

@@ -374,11 +374,16 @@ public:
         }
         stop_.store(true, std::memory_order_release);
         while (active_.load(std::memory_order_acquire) > 0) cpu_relax();
+        stat_busy_ms_ = 0;
+        for (int t = 0; t < nthreads_; ++t) {
+            stat_busy_ms_ += scratch_[t].busy_ms;
+            scratch_[t].busy_ms = 0;
+        }
         return rc;
     }
 
     long stat_stale_ = 0, stat_helped_ = 0;
-    double stat_stale_ms_ = 0;
+    double stat_stale_ms_ = 0, stat_busy_ms_ = 0;
 
 private:
     // neighbour lists live in per-thread chunked pools (no malloc per tag)
@@ -387,6 +392,7 @@ private:
         std::vector<double> vel, mf, mx, my, fq;
         std::vector<int> seen;          // per run: tag already in `consulted`
         int stamp = 0, run_stamp = 0;
+        double busy_ms = 0;
         std::vector<std::unique_ptr<int[]>> chunks;
         size_t chunk_used = 0, chunk_index = 0;
         static constexpr size_t CHUNK = 1 << 16;
@@ -460,7 +466,10 @@ private:
         } else {
             slot.skipped = false;
             slot.epoch = accepted_.load(std::memory_order_acquire);
+            const auto tb = std::chrono::steady_clock::now();
             run_seed(t1, (int)p, s, slot.res);
+            s.busy_ms += std::chrono::duration<double, std::milli>(
+                std::chrono::steady_clock::now() - tb).count();
         }
         slot.state.store(1, std::memory_order_release);
         return true;
@@ -664,6 +673,9 @@ private:
 
             bool bad = false;
             while (!s.frontier.empty()) {
+                // an arc committed meanwhile took this seed: the committer
+                // will skip it, whatever this run would find
+                if (done_[t1].load(std::memory_order_relaxed)) return;
                 // nearest frontier tag: smallest distance, lowest index among
                 // equals.  Compared on squared distances; the roots are only
                 // taken among those within rounding of the smallest.
@@ -1250,9 +1262,10 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
         if (stats)
             fprintf(stderr,
                     "step3: trial pass %.1f ms, full pass %.1f ms (%ld stale "
-                    "results recomputed in %.1f ms, committer ran %ld seeds)\n",
+                    "results recomputed in %.1f ms, committer ran %ld seeds, "
+                    "seed time summed over threads %.1f ms)\n",
                     ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_stale_ms_,
-                    b.stat_helped_);
+                    b.stat_helped_, b.stat_busy_ms_);
     }
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;

@@ -614,7 +614,8 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&b->h_recs, sizeof(BlobRec) * b->cap_blob);
     if (e == hipSuccess)
-        e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
+        e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming |
+                                                  hipEventBlockingSync);
     if (e != hipSuccess) {
         const char *msg = hipGetErrorString(e);
         hk_blob_destroy(b);

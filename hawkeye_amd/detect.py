@@ -201,10 +201,11 @@ class EventDetector:
     """Step-2 arithmetic for a stream of frame chunks: MOG -> blob detector.
 
     ``submit(frames)`` enqueues MOG and blob detection for one chunk and
-    returns the per-frame keypoints of the *previous* chunk (two blob work
-    sets alternate, so the host-side grouping of chunk i overlaps the GPU work
-    of chunk i+1); ``flush()`` returns the last chunk's.  Results come back in
-    frame order: a list with one float32 [n][3] array (x, y, size) per frame.
+    returns the per-frame keypoints of an *earlier* chunk (three work sets
+    rotate, so the blob kernels and the host-side grouping of chunks i-1 and
+    i-2 overlap the MOG of chunk i); ``flush()`` returns what is still in
+    flight.  Results come back in frame order: a list with one float32
+    [n][3] array (x, y, size) per frame.
 
     MOG runs on the caller's current stream; the blob kernels of a chunk run
     on a second stream behind an event, so the (latency-bound) border tracing
@@ -216,26 +217,34 @@ class EventDetector:
             int(chunk)
         self.device = torch.device('cuda', device)
         self.mog = BackgroundSubtractorMOG(width, height, device)
+        # DEPTH work sets rotate: MOG of chunk i is launched while the blob
+        # kernels of chunks i-1 and i-2 may still be running or waiting for
+        # their host-side finish
         self.blob = [SimpleBlobDetector(width, height, blob_params,
                                         max_frames=self.chunk, device=device)
-                     for _ in range(2)]
+                     for _ in range(self.DEPTH)]
         self.masks = [torch.empty((self.chunk, self.height, self.width),
                                   dtype=torch.uint8, device=self.device)
-                      for _ in range(2)]
-        self._cur = 0
-        self._pending = [False, False]
+                      for _ in range(self.DEPTH)]
+        self._next = 0              # chunks submitted so far
+        self._collected = 0         # chunks whose keypoints were returned
         # set to a list to collect (start, end, frames) event triples of the
         # MOG launches, recorded on the stream they run on
         self.mog_timing = None
         self._side = torch.cuda.Stream(device=self.device)
-        self._mog_done = [torch.cuda.Event() for _ in range(2)]
+        self._mog_done = [torch.cuda.Event() for _ in range(self.DEPTH)]
+
+    DEPTH = 3
 
     def submit(self, frames):
         t = frames.shape[0]
         if t == 0 or t > self.chunk:
             raise ValueError('chunk of {} frames (max {})'.format(t,
                                                                    self.chunk))
-        p = self._cur
+        out = []
+        if self._next - self._collected >= self.DEPTH:      # set still busy
+            out = self._collect()
+        p = self._next % self.DEPTH
         masks = self.masks[p][:t]
         main = torch.cuda.current_stream(self.device)
         if self.mog_timing is None:
@@ -250,19 +259,23 @@ class EventDetector:
         self._mog_done[p].record(main)
         self._side.wait_event(self._mog_done[p])
         self.blob[p].enqueue(masks, stream=self._side)
-        self._pending[p] = True
-        self._cur = 1 - p
-        return self._collect(1 - p)
+        self._next += 1
+        # keep DEPTH - 1 chunks in flight behind the one just launched
+        while self._next - self._collected > self.DEPTH - 1:
+            out += self._collect()
+        return out
 
-    def _collect(self, p):
-        if not self._pending[p]:
+    def _collect(self):
+        if self._collected >= self._next:
             return []
-        self._pending[p] = False
+        p = self._collected % self.DEPTH
+        self._collected += 1
         return self.blob[p].finish()
 
     def flush(self):
-        out = self._collect(self._cur)
-        out += self._collect(1 - self._cur)
+        out = []
+        while self._collected < self._next:
+            out += self._collect()
         return out
 
     def close(self):
