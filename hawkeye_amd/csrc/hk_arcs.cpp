@@ -36,32 +36,12 @@ long trunc_to_int(double v) {
     return (long)v;
 }
 
-struct Moments {
-    double T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
-    double X1 = 0, TX = 0, T2X = 0, Y1 = 0, TY = 0, T2Y = 0;
-};
-
 template <class WeightOf>
 Moments moments(const hk_clip &c, const Arc &arc, const std::vector<int> &tags,
                 WeightOf weight_of) {
     Moments m;
-    for (int i : tags) {
-        const double t = c.frame[i] - arc.f_peak;
-        const double w = weight_of(i);
-        const double x = c.x[i], y = c.y[i];
-        const double t2 = t * t;
-        m.T0 += w;
-        m.T1 += w * t;
-        m.T2 += w * t2;
-        m.T3 += w * (t2 * t);
-        m.T4 += w * (t2 * t2);
-        m.X1 += w * x;
-        m.TX += w * t * x;
-        m.T2X += w * t2 * x;
-        m.Y1 += w * y;
-        m.TY += w * t * y;
-        m.T2Y += w * t2 * y;
-    }
+    for (int i : tags)
+        moments_add(m, c.frame[i] - arc.f_peak, weight_of(i), c.x[i], c.y[i]);
     return m;
 }
 
@@ -152,39 +132,13 @@ void fit_one(const hk_clip &c, Arc &arc, const std::vector<int> &tags,
 
 // The normal equations of fit_one, given the moment sums.
 void solve_fit(Arc &arc, const Moments &m, const Rot &rot) {
-    const double T0 = m.T0, T1 = m.T1, T2 = m.T2, T3 = m.T3, T4 = m.T4;
-    const double det2 = T0 * T2 - T1 * T1;
-    const double det3 = 2 * T1 * T2 * T3 + T0 * T2 * T4 - T0 * (T3 * T3) -
-                        (T1 * T1) * T4 - T2 * T2 * T2;
-    if (std::fabs(det2) < 1e-3 || std::fabs(det3) < 1e-3) return;
-    const double s = rot.s, cs = rot.c;
-    const double bx1 = cs * m.TX - s * m.TY;
-    const double bx2 = cs * m.X1 - s * m.Y1;
-    const double b_new = (T0 * bx1 - T1 * bx2) / det2;
-    double a_new = (-T1 * bx1 + T2 * bx2) / det2;
-    const double m11 = T0 * T2 - T1 * T1;
-    const double m12 = T1 * T2 - T0 * T3;
-    const double m13 = T1 * T3 - T2 * T2;
-    const double m22 = T0 * T4 - T2 * T2;
-    const double m23 = T2 * T3 - T1 * T4;
-    const double m33 = T2 * T4 - T3 * T3;
-    const double by1 = cs * m.T2Y + s * m.T2X;
-    const double by2 = cs * m.TY + s * m.TX;
-    const double by3 = cs * m.Y1 + s * m.X1;
-    const double e_new = (m11 * by1 + m12 * by2 + m13 * by3) / det3;
-    const double d_new = (m12 * by1 + m22 * by2 + m23 * by3) / det3;
-    double c_new = (m13 * by1 + m23 * by2 + m33 * by3) / det3;
-    if (std::isnan(a_new) || std::isnan(b_new) || std::isnan(c_new) ||
-        std::isnan(d_new) || std::isnan(e_new) || e_new == 0)
-        return;
-    const double shift = -d_new / (2.0 * e_new);
-    arc.f_peak += shift;
-    a_new += b_new * shift;
-    c_new += d_new * shift + e_new * (shift * shift);
-    arc.a = a_new;
-    arc.b = b_new;
-    arc.c = c_new;
-    arc.e = e_new;
+    double p[5] = {arc.a, arc.b, arc.c, arc.e, arc.f_peak};
+    if (!solve_fit5(p, m, rot.s, rot.c)) return;
+    arc.a = p[0];
+    arc.b = p[1];
+    arc.c = p[2];
+    arc.e = p[3];
+    arc.f_peak = p[4];
 }
 
 // eval_arc with distances computed here (reference tracker.py:800-840).
@@ -222,6 +176,7 @@ int report_progress(hk_clip &c) {
 // Worker threads for step 3.  The box's CPU share is what OMP_NUM_THREADS
 // says (the GPU boxes export 16); never more than 16.
 std::atomic<int> g_host_threads{0};     // hk_set_host_threads(); 0 = auto
+std::atomic<int> g_self_check{getenv("HK_SELF_CHECK") != nullptr};
 
 int worker_count() {
     int n = (int)std::thread::hardware_concurrency();
@@ -840,23 +795,100 @@ void refresh_cache(const hk_clip &c, const Arc &arc, const Rot &rot,
     }
 }
 
-// All of "while self.merge_arcs(arcs): ..." (reference tracker.py:964-965,
-// 1126-1286).  The good-tag lists and frame ranges the reference recomputes
-// for every pair are cached per arc and refreshed only for the arc a merger
-// changed; decisions and their order are unchanged.
-int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
+// One merge_arcs() trial on the host: union of the two good-tag lists, fit,
+// outlier count (reference tracker.py:1199-1233).
+void host_merge_trial(const hk_clip &c, const Arc &a1, const MergeCache &m1,
+                      const MergeCache &m2, const Rot &rot,
+                      std::vector<int> &trial_tags, MergeTrial &out) {
+    trial_tags.clear();
+    std::set_union(m1.good.begin(), m1.good.end(), m2.good.begin(),
+                   m2.good.end(), std::back_inserter(trial_tags));
+    out.p[0] = a1.a;            // copy.copy(arc1): parameters only
+    out.p[1] = a1.b;
+    out.p[2] = a1.c;
+    out.p[3] = a1.e;
+    out.p[4] = a1.f_peak;
+    out.union_n = (int)trial_tags.size();
+    out.poor = 0;
+    if (out.union_n < c.p.min_tags_per_arc) return;
+    if (out.union_n >= 3) {
+        Moments m;
+        const double fp = out.p[4];
+        for (int i : trial_tags)
+            moments_add(m, c.frame[i] - fp, c.tw[i], c.x[i], c.y[i]);
+        solve_fit5(out.p, m, rot.s, rot.c);
+    }
     const double maxd = c.p.max_distance_pixels;
+    for (int i : trial_tags)
+        if (std::sqrt(arc_dist_sq5(out.p, (double)c.frame[i], c.x[i], c.y[i],
+                                   rot.s, rot.c)) > maxd &&
+            ++out.poor > 2)
+            break;
+}
+
+// All of "while self.merge_arcs(arcs): ..." (reference tracker.py:964-965,
+// 1126-1286).  Decisions and their order are the reference's; the work is
+// organised differently:
+//  * the good-tag lists and frame ranges the reference recomputes for every
+//    pair are cached per arc and refreshed only for the arc a merger changed;
+//  * the trial fits of ALL candidate pairs of the pass are evaluated up
+//    front in one kernel launch (K8 merge_trials_k, bit-identical to the
+//    host's trial fit); the scan below then only looks results up, and
+//    computes on the host the pairs that involve an arc changed by a merger
+//    of this pass.
+int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
     const Rot rot = rotation(c);
     std::vector<double> dist;
     std::vector<long> off;
     int rc = em_member_distances(c, stream, dist, off);
     if (rc != HK_OK) return rc;
-    std::vector<MergeCache> cache(c.arcs.size());
-    for (size_t k = 0; k < c.arcs.size(); ++k)
+    const size_t A0 = c.arcs.size();
+    std::vector<MergeCache> cache(A0);
+    for (size_t k = 0; k < A0; ++k)
         refresh_cache(c, c.arcs[k], rot, dist.data() + off[k], cache[k]);
 
-    auto tw_of = [&](int i) { return c.tw[i]; };
+    auto candidate = [&](size_t i1, size_t i2) {    // the cheap tests
+        return !(cache[i2].f_max < cache[i1].f_min ||
+                 cache[i2].f_min > cache[i1].f_max) &&
+               cache[i2].good.size() >= 3;
+    };
+
+    // every pair the scan could reach with the arcs as they are now
+    std::vector<int> pairs, lookup;
+    std::vector<MergeTrial> trials;
+    const bool verify = g_self_check.load() != 0;
+    {
+        for (size_t i1 = 0; i1 < A0; ++i1) {
+            if (c.arcs[i1].done || c.arcs[i1].tags.empty() ||
+                cache[i1].good.size() < 3)
+                continue;
+            for (size_t i2 = 0; i2 < A0; ++i2)
+                if (i2 != i1 && !c.arcs[i2].tags.empty() && candidate(i1, i2)) {
+                    pairs.push_back((int)i1);
+                    pairs.push_back((int)i2);
+                }
+        }
+        if (pairs.size() / 2 >= 128) {      // else not worth a launch
+            std::vector<int> good_off(A0 + 1, 0), good;
+            for (size_t k = 0; k < A0; ++k) {
+                good.insert(good.end(), cache[k].good.begin(),
+                            cache[k].good.end());
+                good_off[k + 1] = (int)good.size();
+            }
+            rc = em_merge_trials(c, stream, good_off, good, pairs, trials);
+            if (rc != HK_OK) return rc;
+            lookup.assign(A0 * A0, -1);
+            for (size_t q = 0; q < pairs.size() / 2; ++q)
+                lookup[(size_t)pairs[2 * q] * A0 + (size_t)pairs[2 * q + 1]] =
+                    (int)q;
+        }
+    }
+    std::vector<int> orig(A0);              // position now -> position then
+    std::iota(orig.begin(), orig.end(), 0);
+    std::vector<char> changed(A0, 0);
+
     std::vector<int> trial_tags;
+    MergeTrial host_trial;
     bool merged = true;
     while (merged) {                    // one iteration = one merge_arcs()
         merged = false;
@@ -874,40 +906,48 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
                     a2.done = true;
                     continue;
                 }
-                if (cache[i2].f_max < cache[i1].f_min ||
-                    cache[i2].f_min > cache[i1].f_max)
-                    continue;
-                if (cache[i2].good.size() < 3) continue;
-                trial_tags.clear();
-                std::set_union(cache[i1].good.begin(), cache[i1].good.end(),
-                               cache[i2].good.begin(), cache[i2].good.end(),
-                               std::back_inserter(trial_tags));
-                if ((int)trial_tags.size() < c.p.min_tags_per_arc) continue;
-                Arc trial;              // copy.copy(arc1): parameters only
-                trial.a = a1.a;
-                trial.b = a1.b;
-                trial.c = a1.c;
-                trial.e = a1.e;
-                trial.f_peak = a1.f_peak;
-                fit_one(c, trial, trial_tags, rot, tw_of);
-                int poor = 0;
-                for (int t : trial_tags)
-                    if (arc_tag_distance(c, trial, rot, t) > maxd &&
-                        ++poor > 2)
-                        break;
-                if (poor > 2) continue;
+                if (!candidate(i1, i2)) continue;
+                const MergeTrial *tr = nullptr;
+                const size_t o1 = (size_t)orig[i1], o2 = (size_t)orig[i2];
+                if (!lookup.empty() && !changed[o1] && !changed[o2] &&
+                    lookup[o1 * A0 + o2] >= 0)
+                    tr = &trials[(size_t)lookup[o1 * A0 + o2]];
+                if (tr == nullptr || verify) {
+                    host_merge_trial(c, a1, cache[i1], cache[i2], rot,
+                                     trial_tags, host_trial);
+                    if (tr != nullptr &&
+                        (tr->union_n != host_trial.union_n ||
+                         tr->poor != host_trial.poor ||
+                         std::memcmp(tr->p, host_trial.p, sizeof(tr->p)) != 0))
+                        return fail(HK_ERR_INTERNAL,
+                                    "merge trial of arcs %zu, %zu differs "
+                                    "between device and host", i1, i2);
+                    tr = &host_trial;
+                }
+                if (tr->union_n < c.p.min_tags_per_arc) continue;
+                if (tr->poor > 2) continue;
 
                 // merge a2 into a1
-                a1.a = trial.a;
-                a1.b = trial.b;
-                a1.c = trial.c;
-                a1.e = trial.e;
-                a1.f_peak = trial.f_peak;
+                if (tr != &host_trial) {
+                    trial_tags.clear();
+                    std::set_union(cache[i1].good.begin(),
+                                   cache[i1].good.end(),
+                                   cache[i2].good.begin(),
+                                   cache[i2].good.end(),
+                                   std::back_inserter(trial_tags));
+                }
+                a1.a = tr->p[0];
+                a1.b = tr->p[1];
+                a1.c = tr->p[2];
+                a1.e = tr->p[3];
+                a1.f_peak = tr->p[4];
                 a1.tags = trial_tags;
                 a1.w_off = -1;
                 refresh_cache(c, a1, rot, nullptr, cache[i1]);
+                changed[o1] = 1;
                 c.arcs.erase(c.arcs.begin() + (long)i2);
                 cache.erase(cache.begin() + (long)i2);
+                orig.erase(orig.begin() + (long)i2);
                 merged = true;
                 merged_any = true;
                 break;
@@ -1370,5 +1410,10 @@ extern "C" int hk_release_cached_memory(void) {
 extern "C" int hk_set_host_threads(int n) {
     if (n < 0) return hk::fail(HK_ERR_ARG, "hk_set_host_threads: %d", n);
     hk::g_host_threads.store(n);
+    return HK_OK;
+}
+
+extern "C" int hk_set_self_check(int on) {
+    hk::g_self_check.store(on != 0);
     return HK_OK;
 }

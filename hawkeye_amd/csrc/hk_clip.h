@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "hk_common.h"
+#include "hk_fit.h"
 
 namespace hk {
 
@@ -49,6 +50,9 @@ struct DeviceState {
     double *list_out = nullptr;         // per list entry result (distances)
     int *h_list = nullptr;              // pinned
     double *h_list_out = nullptr;       // pinned
+    size_t merge_cap = 0;               // bytes
+    char *merge_buf = nullptr;          // merge-trial staging block
+    char *h_merge_buf = nullptr;        // pinned
 };
 
 }  // namespace hk
@@ -109,6 +113,13 @@ int em_tilt(hk_clip &clip, hipStream_t stream);
 int em_member_distances(hk_clip &clip, hipStream_t stream,
                         std::vector<double> &dist,
                         std::vector<long> &offsets);
+// Trial fits of all candidate pairs of a merge pass (reference
+// tracker.py:1199-1233), bit-identical to the host's own trial fit.
+int em_merge_trials(hk_clip &clip, hipStream_t stream,
+                    const std::vector<int> &good_off,
+                    const std::vector<int> &good,
+                    const std::vector<int> &pairs,
+                    std::vector<MergeTrial> &out);
 // Host decision shared by em_tilt and the arc evaluators.
 bool acceleration_ok(const hk_clip &clip, double e);
 

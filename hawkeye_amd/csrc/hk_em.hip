@@ -249,6 +249,62 @@ __global__ __launch_bounds__(64) void member_dist_k(
     }
 }
 
+// K8 merge trials: one lane per candidate pair of arcs (reference
+// tracker.py:1199-1233).  The lane walks the union of the two arcs' good-tag
+// lists in ascending tag order -- the order, and through hk_fit.h the
+// operations, of the host's own trial fit, so the result is the same bit for
+// bit -- fits the trial parabola and counts the tags it leaves farther than
+// max_distance_pixels (up to 3).  Latency-bound: ~10^3-10^4 pairs of ~10^2
+// tags; what it buys is all trial fits of a merge pass in one launch.
+__global__ __launch_bounds__(64) void merge_trials_k(
+    TagArrays tg, const double *__restrict__ params5,
+    const int *__restrict__ good_off, const int *__restrict__ good,
+    const int *__restrict__ pairs, int npairs, hk::MergeTrial *__restrict__ out,
+    double sn, double cs, double maxd, int min_tags) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= npairs) return;
+    const int i1 = pairs[2 * q], i2 = pairs[2 * q + 1];
+    const int lo1 = good_off[i1], hi1 = good_off[i1 + 1];
+    const int lo2 = good_off[i2], hi2 = good_off[i2 + 1];
+    hk::MergeTrial r;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) r.p[j] = params5[5 * i1 + j];
+    r.poor = 0;
+
+    hk::Moments m;
+    int n = 0;
+    {
+        const double fp = r.p[4];
+        int a = lo1, b = lo2;
+        while (a < hi1 || b < hi2) {
+            const int ta = a < hi1 ? good[a] : 0x7fffffff;
+            const int tb = b < hi2 ? good[b] : 0x7fffffff;
+            const int t = ta < tb ? ta : tb;
+            a += (ta == t);
+            b += (tb == t);
+            hk::moments_add(m, tg.frame[t] - fp, tg.tw[t], tg.x[t], tg.y[t]);
+            ++n;
+        }
+    }
+    r.union_n = n;
+    if (n >= min_tags) {
+        if (n >= 3) hk::solve_fit5(r.p, m, sn, cs);
+        int a = lo1, b = lo2, poor = 0;
+        while ((a < hi1 || b < hi2) && poor <= 2) {
+            const int ta = a < hi1 ? good[a] : 0x7fffffff;
+            const int tb = b < hi2 ? good[b] : 0x7fffffff;
+            const int t = ta < tb ? ta : tb;
+            a += (ta == t);
+            b += (tb == t);
+            const double d = sqrt(hk::arc_dist_sq5(r.p, (double)tg.frame[t],
+                                                   tg.x[t], tg.y[t], sn, cs));
+            if (d > maxd) ++poor;
+        }
+        r.poor = poor;
+    }
+    out[q] = r;
+}
+
 template <class T>
 hipError_t dev_alloc(T *&p, size_t count) {
     return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1));
@@ -409,6 +465,7 @@ void free_workspace(DeviceState &d) {
     (void)hipHostFree(d.h_arc_params); (void)hipHostFree(d.h_arc_win);
     (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_bitmap);
     (void)hipHostFree(d.h_list); (void)hipHostFree(d.h_list_out);
+    (void)hipFree(d.merge_buf); (void)hipHostFree(d.h_merge_buf);
     d = DeviceState();
 }
 
@@ -473,7 +530,7 @@ int em_prepare(hk_clip &c, hipStream_t s) {
 void em_release(hk_clip &c) {
     DeviceState &d = c.dev;
     if (!d.tag_cap && !d.arc_cap && !d.weight_cap && !d.bitmap_cap &&
-        !d.list_cap)
+        !d.list_cap && !d.merge_cap)
         return;
     d.ready = false;
     {
@@ -647,6 +704,69 @@ int em_member_distances(hk_clip &c, hipStream_t s, std::vector<double> &dist,
                           hipMemcpyDeviceToHost, s));
     HK_HIP(hipStreamSynchronize(s));
     std::copy(d.h_list_out, d.h_list_out + total, dist.begin());
+    return HK_OK;
+}
+
+// All candidate pairs of a merge pass in one launch.  good_off/good: the
+// arcs' good-tag lists (CSR over the current arc list); pairs: (i1, i2)
+// positions in that list.
+int em_merge_trials(hk_clip &c, hipStream_t s, const std::vector<int> &good_off,
+                    const std::vector<int> &good, const std::vector<int> &pairs,
+                    std::vector<MergeTrial> &out) {
+    DeviceState &d = c.dev;
+    DeviceGuard guard(c.device);
+    const size_t A = c.arcs.size();
+    const size_t npairs = pairs.size() / 2;
+    out.resize(npairs);
+    if (npairs == 0) return HK_OK;
+    // one staging block: params | good_off | good | pairs, then the results
+    const size_t b_params = 0;
+    const size_t b_off = b_params + sizeof(double) * 5 * A;
+    const size_t b_good = b_off + sizeof(int) * (A + 1);
+    const size_t b_pairs = b_good + sizeof(int) * good.size();
+    size_t b_out = b_pairs + sizeof(int) * pairs.size();
+    b_out = (b_out + 15) & ~(size_t)15;
+    const size_t total = b_out + sizeof(MergeTrial) * npairs;
+    if (total > d.merge_cap) {
+        const size_t cap = std::max(total * 2, (size_t)1 << 20);
+        (void)hipFree(d.merge_buf);
+        (void)hipHostFree(d.h_merge_buf);
+        d.merge_buf = nullptr;
+        d.h_merge_buf = nullptr;
+        d.merge_cap = 0;
+        HK_HIP(dev_alloc(d.merge_buf, cap));
+        HK_HIP(pin_alloc(d.h_merge_buf, cap));
+        d.merge_cap = cap;
+    }
+    char *h = d.h_merge_buf;
+    double *hp = reinterpret_cast<double *>(h + b_params);
+    for (size_t k = 0; k < A; ++k) {
+        const Arc &arc = c.arcs[k];
+        hp[5 * k] = arc.a;
+        hp[5 * k + 1] = arc.b;
+        hp[5 * k + 2] = arc.c;
+        hp[5 * k + 3] = arc.e;
+        hp[5 * k + 4] = arc.f_peak;
+    }
+    std::memcpy(h + b_off, good_off.data(), sizeof(int) * (A + 1));
+    std::memcpy(h + b_good, good.data(), sizeof(int) * good.size());
+    std::memcpy(h + b_pairs, pairs.data(), sizeof(int) * pairs.size());
+    HK_HIP(hipMemcpyAsync(d.merge_buf, h, b_out, hipMemcpyHostToDevice, s));
+    const Rot rot = rotation(c);
+    char *g = d.merge_buf;
+    hipLaunchKernelGGL(merge_trials_k, dim3((unsigned)((npairs + 63) / 64)),
+                       dim3(64), 0, s, tag_arrays(d),
+                       reinterpret_cast<const double *>(g + b_params),
+                       reinterpret_cast<const int *>(g + b_off),
+                       reinterpret_cast<const int *>(g + b_good),
+                       reinterpret_cast<const int *>(g + b_pairs), (int)npairs,
+                       reinterpret_cast<MergeTrial *>(g + b_out), rot.s, rot.c,
+                       c.p.max_distance_pixels, c.p.min_tags_per_arc);
+    HK_LAUNCH_CHECK("merge_trials_k");
+    HK_HIP(hipMemcpyAsync(h + b_out, g + b_out, sizeof(MergeTrial) * npairs,
+                          hipMemcpyDeviceToHost, s));
+    HK_HIP(hipStreamSynchronize(s));
+    std::memcpy(out.data(), h + b_out, sizeof(MergeTrial) * npairs);
     return HK_OK;
 }
 

@@ -177,6 +177,8 @@ int hk_render_frames(int width, int height, float fps, unsigned seed,
  *      tilt        estimate_camera_tilt (reference tracker.py:1041-1124)
  *   K7 distances   Ballarc.get_distance_from_tag over arc members
  *                                      (reference types.py:70-72)
+ *   K8 merge trials  the trial fits of all candidate arc pairs of a
+ *                  merge_arcs pass    (reference tracker.py:1199-1233)
  * as fp64 HIP kernels on `device`, one wavefront per arc.
  * ---------------------------------------------------------------------- */
 typedef struct hk_scan_params {
@@ -244,6 +246,12 @@ int hk_clip_build_initial_arcs(hk_clip *c);
 int hk_set_host_threads(int n);
 /* Step 4.  Synchronises `stream` as needed. */
 int hk_clip_em_optimize(hk_clip *c, void *stream);
+
+/* Debug aid: with on != 0 (or HK_SELF_CHECK set in the environment) every
+ * merge trial fit that step 4 takes from the device (K8) is recomputed on the
+ * host and must match bit for bit, else the step fails with
+ * HK_ERR_INTERNAL. */
+int hk_set_self_check(int on);
 
 /* The individual EM operations, as VideoScanner exposes them. */
 int hk_clip_calculate_weights(hk_clip *c, void *stream);

@@ -152,3 +152,29 @@ def test_empty_and_tiny_clips():
     assert len(clip.arcs()[0]) == 0
     alive, final = clip.tag_state()
     assert (final == -1).all()
+
+
+def test_device_merge_trials_equal_host_trials():
+    """K8: with the self-check on, every trial fit taken from the device is
+    recomputed on the host and must match bit for bit (the step fails
+    otherwise); the outcome must also equal the run without the check.  The
+    noisy 1080p input has thousands of candidate pairs and ~35 mergers."""
+    from hawkeye_amd import _native as nat
+    scene = synth.JugglingScene(1920, 1080, 60.0, 9, 600, 611)
+    meas = synth.make_tags(scene, 612, clutter_per_frame=25.0)
+    outcomes = []
+    for check in (1, 0):
+        nat.check(nat.lib.hk_set_self_check(check))
+        try:
+            clip, _ = make_clip(meas, 1920, 1080, 60.0, 600)
+            clip.build_initial_arcs()
+            n3 = len(clip.arcs()[0])
+            clip.em_optimize()
+            params, ids, tags = clip.arcs()
+            outcomes.append((n3, params.tobytes(), ids.tobytes(),
+                             [t.tobytes() for t in tags]))
+            clip.close()
+        finally:
+            nat.check(nat.lib.hk_set_self_check(0))
+    assert outcomes[0] == outcomes[1]
+    assert len(outcomes[0][3]) < outcomes[0][0]        # mergers happened
