@@ -15,9 +15,12 @@ What is kept from the reference, because callers depend on it
   * progress text through ``print`` gated by ``verbosity``
   * ``ScannerException`` for an unopenable video
 
-Steps 5-6 (YOLO body detection, juggling analysis) are outside the
-accelerated path: they stay the reference's own host code, see
-INTEGRATION.md for how a maintainer binds them.
+Step 5 (YOLO body detection) stays host code outside this build: a detector
+can be plugged in (``body_detector``), else body positions are estimated in
+step 6 the way the reference does for frames its detector missed.  Step 6
+(juggling analysis, hawkeye_amd/juggling.py) is the reference's host-side
+post-processing of the final arcs, restated and checked against golden
+vectors from the reference.
 """
 import os
 import pickle
@@ -41,8 +44,9 @@ class VideoScanner:
     DETECT_CHUNK = 128
 
     def __init__(self, filename, scanvideo=None, params=None, notes=None,
-                 device=0):
+                 device=0, body_detector=None):
         self.device = device
+        self.body_detector = body_detector
         if notes is None:
             self.notes = {
                 'version': VideoScanner.CURRENT_NOTES_VERSION,
@@ -384,20 +388,41 @@ class VideoScanner:
         return code
 
     # ------------------------------------------------------------------
-    #  steps 5-6: outside the accelerated path
+    #  step 5: YOLO body detection stays on the host (north_star)
     # ------------------------------------------------------------------
 
     def detect_juggler(self, display=False):
-        raise ScannerException(
-            'step 5 (YOLO body detection, reference tracker.py:1441-1779) is '
-            'outside the accelerated path; bind the reference method as '
-            'INTEGRATION.md shows')
+        """The reference runs a YOLOv2-tiny person detector through cv2.dnn
+        here (reference tracker.py:1441-1779); that model is outside this
+        build.  A host-side detector can be plugged in as ``body_detector``
+        (a callable taking the scanner and returning {frame: (x, y, w, h,
+        True)} in source-video pixels).  Without one, notes['body'] is left
+        empty and step 6 estimates every body box from the tags -- the
+        reference's own fallback for frames its detector missed."""
+        notes = self.notes
+        if self.body_detector is not None:
+            self._say(1, 'Juggler detection starting...')
+            notes['body'] = dict(self.body_detector(self))
+            self._say(1, 'Juggler detection done: {} frames'.format(
+                len(notes['body'])))
+        else:
+            notes['body'] = dict()
+            self._say(1, 'Juggler detection skipped (no body detector): body '
+                         'positions will be estimated from the detected '
+                         'objects\n')
+
+    # ------------------------------------------------------------------
+    #  step 6 (reference tracker.py:1785-2504): host post-processing
+    # ------------------------------------------------------------------
 
     def analyze_juggling(self):
-        raise ScannerException(
-            'step 6 (juggling analysis, reference tracker.py:1785-2504) is '
-            'outside the accelerated path; bind the reference method as '
-            'INTEGRATION.md shows')
+        from . import juggling
+        if 'body' not in self.notes:
+            self.notes['body'] = dict()
+        juggling.analyze_juggling(self.notes, say=self._say,
+                                  progress=(self._progress
+                                            if getattr(self, '_callback', None)
+                                            is not None else None))
 
     # ------------------------------------------------------------------
     #  statics (reference tracker.py:2510-2607)

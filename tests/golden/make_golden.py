@@ -32,9 +32,15 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 
 sys.modules.setdefault('cv2', types.ModuleType('cv2'))
-sys.path.insert(0, '/root/reference')
+# The repository has its own `hawkeye` package (the drop-in shim), and a
+# regular package wins over the reference's __init__-less directory whatever
+# the path order: bind the name `hawkeye` to the reference's directory by hand.
+_ref_pkg = types.ModuleType('hawkeye')
+_ref_pkg.__path__ = ['/root/reference/hawkeye']
+sys.modules['hawkeye'] = _ref_pkg
 import hawkeye.tracker as ref_tracker            # noqa: E402
 import hawkeye.types as ref_types                # noqa: E402
+assert ref_tracker.__file__.startswith('/root/reference/')
 
 from hawkeye_amd import synth                    # noqa: E402
 
@@ -133,6 +139,8 @@ def full_run(name, spec):
         'tags_remaining': len(final_assign),
     }
 
+    step6 = step6_vectors(sc, notes, idx, frames)
+
     out = {
         'name': name,
         'width': width, 'height': height, 'fps': fps, 'frames': frames,
@@ -141,6 +149,7 @@ def full_run(name, spec):
         'meas': {str(f): [list(t) for t in meas[f]] for f in range(frames)},
         'step3': step3,
         'step4': step4,
+        'step6': step6,
     }
     path = os.path.join(HERE, 'run_{}.json'.format(name))
     with open(path, 'w') as fh:
@@ -148,6 +157,66 @@ def full_run(name, spec):
     print('{}: {} tags, {} arcs after step 3, {} after step 4 -> {}'.format(
         name, sum(len(v) for v in meas.values()), len(step3['arcs']),
         len(step4['arcs']), os.path.basename(path)))
+
+
+STEP6_ARC_FIELDS = ('f_throw', 'x_throw', 'f_catch', 'x_catch', 'height',
+                    'run_id', 'throw_id', 'hand_throw', 'hand_catch',
+                    'throw_error_s', 'throw_error_cm', 'catch_error_s',
+                    'catch_error_cm')
+RUN_FIELDS = ('throws', 'frame range', 'duration', 'height', 'throws per sec',
+              'balls', 'width', 'target throw point cm',
+              'target catch point cm')
+
+
+def step6_vectors(sc, notes, idx, frames):
+    """Runs the reference's analyze_juggling() on the step-4 notes, twice:
+    with no body measurements at all (what a run without the YOLO step 5
+    leaves; every origin is estimated from the tags) and with a body box on
+    a subset of frames.  Step 6 mutates notes, so each variant works on a
+    deep copy."""
+    out = {}
+    for variant in ('no_body', 'some_body'):
+        n = copy.deepcopy(notes)
+        # tags of the copy, keyed like the originals
+        cidx = {}
+        for f in range(frames):
+            for t_orig, t_copy in zip(notes['meas'][f], n['meas'][f]):
+                cidx[id(t_copy)] = idx[id(t_orig)]
+        n['body'] = {}
+        if variant == 'some_body':
+            w, h = n['frame_width'], n['frame_height']
+            for f in range(0, frames, 3):
+                if f % 21 == 0:
+                    continue
+                n['body'][f] = (0.40 * w + 0.02 * w * math.sin(f / 17.0),
+                                0.55 * h, 0.2 * w, 0.4 * h, True)
+        body_in = {str(f): list(v) for f, v in n['body'].items()}
+        s6 = make_scanner(n)
+        s6.process(steps=(6, 6))
+        arcs = []
+        for a in n['arcs']:
+            d = {k: getattr(a, k) for k in STEP6_ARC_FIELDS}
+            d['id'] = a.id_
+            d['prev'] = a.prev.id_ if a.prev is not None else None
+            d['next'] = a.next.id_ if a.next is not None else None
+            d['tags'] = sorted(cidx[id(t)] for t in a.tags)
+            arcs.append(d)
+        runs = []
+        for r in n['run']:
+            d = {k: r[k] for k in RUN_FIELDS}
+            d['frame range'] = list(d['frame range'])
+            d['throw'] = [a.id_ for a in r['throw']]
+            runs.append(d)
+        out[variant] = {
+            'body_in': body_in,
+            'runs': n['runs'],
+            'run': runs,
+            'arcs': arcs,
+            'origin': {str(f): list(v) for f, v in n['origin'].items()},
+            'body_out': {str(f): list(v) for f, v in n['body'].items()},
+            'meas_remaining': sum(len(n['meas'][f]) for f in range(frames)),
+        }
+    return out
 
 
 # ---------------------------------------------------------------------------

@@ -193,5 +193,51 @@ def test_abort_and_errors(clip_path, tmp_path):
         VideoScanner(str(tmp_path / 'missing.mov')).process(steps=(1, 1))
     ok = VideoScanner(path)
     ok.process(steps=(1, 4))
-    with pytest.raises(ScannerException, match='step 5'):
-        ok.process(steps=(5, 5))
+    assert len(ok.notes['arcs']) > 0
+
+
+def test_all_six_steps_and_the_notes_file(clip_path, tmp_path):
+    """process(steps=(1, 6)) end to end, the way worker.py calls it
+    (reference worker.py:757-759): step 5 without a detector leaves body
+    positions to step 6's estimate; a plugged-in detector is used; the final
+    notes file is `<base>_notes.pkl` and unpickles with hawkeye.types."""
+    import pickle
+    from hawkeye_amd.tracker import VideoScanner
+    path = clip_path(SPEC, 'six.mov')
+    calls = []
+    sc = VideoScanner(path)
+    sc.process(steps=(1, 6), writenotes=True, notesdir=str(tmp_path / 'n'),
+               callback=lambda *a: calls.append(a), verbosity=0)
+    n = sc.notes
+    assert n['step'] == 6 and n['runs'] == len(n['run']) >= 1
+    assert all(b[4] is False for b in n['body'].values())
+    arcs = n['arcs']
+    assert arcs and all(a.run_id is not None and a.throw_id is not None and
+                        a.hand_throw in ('left', 'right') and
+                        a.hand_catch in ('left', 'right') and
+                        a.f_throw < a.f_peak < a.f_catch for a in arcs)
+    for info in n['run']:
+        assert info['throws'] == len(info['throw']) >= 2
+        assert 1 <= info['balls'] <= info['throws']
+        first, last = info['frame range']
+        assert all(f in n['origin'] or not (first <= f <= last)
+                   for f in range(n['frame_count']))
+    assert () in calls                          # callback() once per run
+    saved = tmp_path / 'n' / 'six_notes.pkl'
+    assert saved.exists()
+    with open(saved, 'rb') as fh:
+        back = pickle.load(fh)
+    assert type(back['arcs'][0]).__module__ == 'hawkeye.types'
+    assert [a.throw_id for a in back['arcs']] == [a.throw_id for a in arcs]
+    assert back['arcs'][0].tags and \
+        all(t.arc is back['arcs'][0] for t in back['arcs'][0].tags)
+
+    # with a body detector plugged into step 5
+    w, h = SPEC['width'], SPEC['height']
+    boxes = {f: (0.4 * w, 0.62 * h, 0.2 * w, 0.35 * h, True)
+             for f in range(0, SPEC['frames'], 2)}
+    sc2 = VideoScanner(path, body_detector=lambda scanner: boxes)
+    sc2.process(steps=(1, 6))
+    assert sum(1 for b in sc2.notes['body'].values() if b[4]) == len(boxes)
+    assert sc2.notes['runs'] == len(sc2.notes['run'])
+    assert sc2.notes['step'] == 6
