@@ -96,3 +96,41 @@ def test_rejects_unsorted_frames():
     with pytest.raises(nat.NativeError, match='ascending'):
         Clip(64, 48, 30.0, 10, [3, 2], [1.0, 2.0], [1.0, 2.0], [5.0, 5.0],
              stream=0)
+
+
+def test_result_does_not_depend_on_thread_count_or_window(monkeypatch):
+    """The speculative builder must give the sequential result bit for bit:
+    same arcs for 1 thread (no speculation at all), several threads, and a
+    speculation window from minimal to very deep.  Input with clutter and
+    slowly moving distractor tracks, so that many seeds grow long trial arcs
+    and accepted arcs invalidate speculative results."""
+    from hawkeye_amd import _native as nat
+    scene = synth.JugglingScene(1280, 720, 60.0, 7, 400, 901)
+    meas = synth.make_tags(scene, 902, clutter_per_frame=15.0)
+    rng = np.random.RandomState(903)
+    for d in range(6):                      # random-walk distractors
+        px, py = rng.uniform(100, 1100), rng.uniform(100, 600)
+        for f in range(400):
+            px += rng.normal(0, 1.2)
+            py += rng.normal(0, 1.2)
+            meas.setdefault(f, []).append((px, py, 14.0 + d))
+    frame, x, y, r, tw, start = synth.tags_to_soa(meas, 400)
+
+    def run(threads, window):
+        monkeypatch.setenv('HK_STEP3_WINDOW', str(window))
+        nat.check(nat.lib.hk_set_host_threads(threads))
+        try:
+            clip = Clip(1280, 720, 60.0, 400, frame, x, y, r, tw, stream=0)
+            clip.build_initial_arcs()
+            params, ids, tags = clip.arcs()
+            g = clip.state()['g_px_per_frame_sq']
+            clip.close()
+        finally:
+            nat.check(nat.lib.hk_set_host_threads(0))
+        return (params.tobytes(), ids.tobytes(),
+                tuple(t.tobytes() for t in tags), g)
+
+    want = run(1, 16)
+    assert len(want[2]) > 20
+    for threads, window in ((2, 1), (4, 16), (8, 256), (16, 1024), (3, 7)):
+        assert run(threads, window) == want, (threads, window)
