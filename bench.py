@@ -145,6 +145,8 @@ def main():
     ap.add_argument('--host-threads', type=int, default=None,
                     help='step-3 worker threads in the pipelined run '
                          '(default: host cores - 2, at most 14)')
+    ap.add_argument('--builders', type=int, default=2,
+                    help='clips in step 3 at the same time (pipelined run)')
     ap.add_argument('--host-frames', type=int, default=512,
                     help='frames of the PCIe-inclusive side measurement '
                          '(0 = skip)')
@@ -195,7 +197,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for result in scanner.scan_many((frames for _ in range(args.steps)),
-                                    host_threads=args.host_threads):
+                                    host_threads=args.host_threads,
+                                    builders=args.builders):
         for k in stage_s:
             stage_s[k] += result.stage_seconds[k]
     barrier()
@@ -253,8 +256,9 @@ def main():
                                             launch_frames),
         'kernel_fps': round(launch_frames / (launch_ms * 1e-3), 1),
         'note': 'model stays in registers across the frames of a launch, so '
-                'physical traffic is ~6.5 B/px/frame, not 324: frac > 1 is '
-                'real, the kernel is VALU-bound (DESIGN.md)',
+                'physical traffic is ~9 B/px/frame (see traffic), not the '
+                'algorithmic 324: frac > 1 is real, the kernel is bound by '
+                'VALU issue, not HBM (DESIGN.md section 4)',
     }
     if traffic is not None:
         roofline['traffic_source'] = traffic.get('source')

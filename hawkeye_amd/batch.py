@@ -14,10 +14,10 @@ out as NumPy arrays, through the same C ABI.
 Step 2 is GPU work (MOG + blob kernels) with a thin host loop; steps 3-4 are
 host work (multi-threaded step 3, merge / prune control flow) around small
 EM kernels.  ``scan_many`` therefore runs them as a three-stage pipeline:
-one worker thread detects clip i+2 on its own HIP stream, another runs step 3
-of clip i+1 on the host cores, and the calling thread runs step 4 of clip i
-(EM kernels on a second stream).  Results are the same as
-scanning the clips one by one, in the same order.
+one worker thread detects the clips ahead on its own HIP stream, two more run
+step 3 of the next two clips on the host cores, and the calling thread runs
+step 4 of the earliest unfinished clip (EM kernels on a second stream).
+Results are the same as scanning the clips one by one, in the same order.
 """
 import os
 import queue
@@ -178,15 +178,19 @@ class ClipScanner:
         self._stage(res, 'detect', time.perf_counter() - t0)
         return self.refine_arcs(*self.build_arcs(per_frame, res))
 
-    def scan_many(self, clips, host_threads=None):
+    def scan_many(self, clips, host_threads=None, builders=2):
         """Generator over the results of `clips` (an iterable of frame
         tensors / sources of this scanner's size), in order.  Three stages
-        run side by side: detection of clip i+2 (GPU, worker thread), step 3
-        of clip i+1 (host cores, worker thread) and step 4 of clip i (calling
-        thread)."""
-        detected = queue.Queue(maxsize=1)
-        built = queue.Queue(maxsize=1)
+        run side by side: detection of later clips (GPU, one worker thread),
+        step 3 (host cores; `builders` clips at a time, each on
+        `host_threads` worker threads, so that the serial parts of one build
+        overlap the parallel parts of another) and step 4 of the earliest
+        unfinished clip (calling thread)."""
+        builders = max(1, int(builders))
+        detected = queue.Queue(maxsize=builders)
+        built = queue.Queue(maxsize=builders)
         stop = threading.Event()
+        END = object()
 
         def put(q, item):
             while not stop.is_set():
@@ -203,9 +207,10 @@ class ClipScanner:
                     return q.get(timeout=0.05)
                 except queue.Empty:
                     pass
-            return None
+            return END
 
         def detect_stage():
+            seq = 0
             try:
                 torch.cuda.set_device(self.device)
                 for frames in clips:
@@ -215,51 +220,78 @@ class ClipScanner:
                     per_frame = self.detect(frames)
                     res = ClipResult()
                     self._stage(res, 'detect', time.perf_counter() - t0)
-                    if not put(detected, (per_frame, res)):
+                    if not put(detected, (seq, per_frame, res)):
                         return
-                put(detected, None)
+                    seq += 1
             except BaseException as exc:    # noqa: B902 - re-raised below
-                put(detected, exc)
+                put(built, (seq, exc))
+            finally:
+                for _ in range(builders):
+                    put(detected, END)
 
         def build_stage():
             try:
                 torch.cuda.set_device(self.device)
                 while True:
                     item = get(detected)
-                    if item is None or isinstance(item, BaseException):
-                        put(built, item)
+                    if item is END:
                         return
-                    if not put(built, self.build_arcs(*item)):
-                        item = None
+                    seq, per_frame, res = item
+                    try:
+                        done = self.build_arcs(per_frame, res)
+                    except BaseException as exc:    # noqa: B902
+                        put(built, (seq, exc))
                         return
-            except BaseException as exc:    # noqa: B902 - re-raised below
-                put(built, exc)
+                    if not put(built, (seq, done)):
+                        done[1].close()
+                        return
+            finally:
+                put(built, END)
 
         # leave cores to the detection loop and to step 4 while step 3 runs
         if host_threads is None:
             cores = min(os.cpu_count() or 1,
                         int(os.environ.get('OMP_NUM_THREADS', '16')), 16)
-            host_threads = max(1, cores - 2)
+            host_threads = max(1, (cores - 2) // builders)
         nat.check(nat.lib.hk_set_host_threads(int(host_threads)))
-        workers = [threading.Thread(target=detect_stage, daemon=True),
-                   threading.Thread(target=build_stage, daemon=True)]
+        workers = [threading.Thread(target=detect_stage, daemon=True)] + \
+            [threading.Thread(target=build_stage, daemon=True)
+             for _ in range(builders)]
         for w in workers:
             w.start()
+        waiting = {}            # seq -> built clip or exception, out of order
         try:
+            want = 0
+            ended = 0
             while True:
-                item = built.get()
-                if item is None:
+                while want in waiting:
+                    item = waiting.pop(want)
+                    if isinstance(item, BaseException):
+                        raise item
+                    want += 1
+                    yield self.refine_arcs(*item)
+                if ended == builders:
                     break
+                item = built.get()
+                if item is END:
+                    ended += 1
+                else:
+                    waiting[item[0]] = item[1]
+            for item in waiting.values():       # after a gap: an error
                 if isinstance(item, BaseException):
                     raise item
-                yield self.refine_arcs(*item)
         finally:
             stop.set()
             for w in workers:
                 w.join()
+            leftovers = list(waiting.values())
             for q in (detected, built):     # close clips nobody will refine
                 while not q.empty():
                     item = q.get_nowait()
-                    if isinstance(item, tuple) and isinstance(item[1], Clip):
-                        item[1].close()
+                    if item is not END:
+                        leftovers.append(item[-1])
+            for item in leftovers:
+                if isinstance(item, tuple) and len(item) == 2 and \
+                        isinstance(item[1], Clip):
+                    item[1].close()
             nat.check(nat.lib.hk_set_host_threads(0))

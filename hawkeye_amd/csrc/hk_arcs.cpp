@@ -339,6 +339,7 @@ public:
 
     long stat_stale_ = 0, stat_helped_ = 0;
     double stat_stale_ms_ = 0, stat_busy_ms_ = 0;
+    bool collect_stats_ = false;       // HK_STEP3_STATS: time every seed
 
 private:
     // neighbour lists live in per-thread chunked pools (no malloc per tag)
@@ -421,10 +422,14 @@ private:
         } else {
             slot.skipped = false;
             slot.epoch = accepted_.load(std::memory_order_acquire);
-            const auto tb = std::chrono::steady_clock::now();
-            run_seed(t1, (int)p, s, slot.res);
-            s.busy_ms += std::chrono::duration<double, std::milli>(
-                std::chrono::steady_clock::now() - tb).count();
+            if (!collect_stats_) {
+                run_seed(t1, (int)p, s, slot.res);
+            } else {
+                const auto tb = std::chrono::steady_clock::now();
+                run_seed(t1, (int)p, s, slot.res);
+                s.busy_ms += std::chrono::duration<double, std::milli>(
+                    std::chrono::steady_clock::now() - tb).count();
+            }
         }
         slot.state.store(1, std::memory_order_release);
         return true;
@@ -1290,6 +1295,7 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
     const auto t0 = now();
     {
         hk::ArcBuilder b(*c);
+        b.collect_stats_ = stats;
         // trial pass: a few confident arcs to estimate gravity
         int rc = b.construct(5, arcs);
         if (rc != HK_OK) return rc;
