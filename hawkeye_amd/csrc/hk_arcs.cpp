@@ -220,6 +220,24 @@ public:
         std::stable_sort(queue_.begin(), queue_.end(),
                          [&](int p, int q) { return c.y[p] < c.y[q]; });
         for (int k = 0; k < n_; ++k) qpos_[(size_t)queue_[(size_t)k]] = k;
+        // per frame, the tags ordered by x (for the neighbour search)
+        xs_idx_.resize((size_t)c.n);
+        xs_val_.resize((size_t)c.n);
+        std::iota(xs_idx_.begin(), xs_idx_.end(), 0);
+        x_index_ok_ = true;
+        for (int i = 0; i < c.n && x_index_ok_; ++i)
+            x_index_ok_ = std::isfinite(c.x[i]) && std::isfinite(c.y[i]);
+        if (x_index_ok_) {
+            for (int f = 0; f < c.F; ++f)
+                std::sort(xs_idx_.begin() + c.start[f],
+                          xs_idx_.begin() + c.start[f + 1],
+                          [&](int p, int q) {
+                              return c.x[p] < c.x[q] ||
+                                     (c.x[p] == c.x[q] && p < q);
+                          });
+            for (int k = 0; k < c.n; ++k)
+                xs_val_[(size_t)k] = c.x[xs_idx_[(size_t)k]];
+        }
         nthreads_ = worker_count();
         scratch_.reset(new Scratch[(size_t)nthreads_]);
         for (int t = 0; t < nthreads_; ++t) scratch_[t].init(c.n, c.F);
@@ -502,23 +520,56 @@ private:
         const int hi = std::min(c.F, f + gap + 2);
         s.cand.clear();
         s.vel.clear();
-        for (int j = c.start[lo]; j < c.start[hi]; ++j) {
-            if (c.frame[j] == f) continue;
-            const double dx = c.x[j] - c.x[i], dy = c.y[j] - c.y[i];
-            const double v = std::sqrt(dx * dx + dy * dy) /
-                             std::abs(c.frame[j] - f);
-            // the speed cap does not depend on the order: apply it before
-            // the sort (same list as sorting first and filtering after)
-            if (has_vmax_ && !(v <= v_max_)) continue;
-            s.cand.push_back(j);
-            s.vel.push_back(v);
+        if (has_vmax_ && x_index_ok_) {
+            // with a speed cap only tags within v_max * |df| can qualify:
+            // visit just the x-window of every frame (tags sorted by x per
+            // frame), then order by (speed, tag index), which is what the
+            // stable sort below gives for candidates met in index order
+            const double xi = c.x[i], yi = c.y[i];
+            for (int g = lo; g < hi; ++g) {
+                if (g == f) continue;
+                const int df = std::abs(g - f);
+                const double r = v_max_ * df * (1 + 1e-12) + 1e-9;
+                const double *xb = xs_val_.data() + c.start[g];
+                const double *xe = xs_val_.data() + c.start[g + 1];
+                for (const double *p = std::lower_bound(xb, xe, xi - r);
+                     p < xe && *p <= xi + r; ++p) {
+                    const int j = xs_idx_[(size_t)(p - xs_val_.data())];
+                    const double dx = c.x[j] - xi, dy = c.y[j] - yi;
+                    const double v = std::sqrt(dx * dx + dy * dy) / df;
+                    if (!(v <= v_max_)) continue;
+                    s.cand.push_back(j);
+                    s.vel.push_back(v);
+                }
+            }
+            const size_t m = s.cand.size();
+            s.order.resize(m);
+            std::iota(s.order.begin(), s.order.end(), 0);
+            std::sort(s.order.begin(), s.order.end(), [&](int p, int q) {
+                return s.vel[p] < s.vel[q] ||
+                       (s.vel[p] == s.vel[q] && s.cand[p] < s.cand[q]);
+            });
+        } else {
+            for (int j = c.start[lo]; j < c.start[hi]; ++j) {
+                if (c.frame[j] == f) continue;
+                const double dx = c.x[j] - c.x[i], dy = c.y[j] - c.y[i];
+                const double v = std::sqrt(dx * dx + dy * dy) /
+                                 std::abs(c.frame[j] - f);
+                // the speed cap does not depend on the order: apply it
+                // before the sort (same list as sorting first and filtering
+                // after)
+                if (has_vmax_ && !(v <= v_max_)) continue;
+                s.cand.push_back(j);
+                s.vel.push_back(v);
+            }
+            s.order.resize(s.cand.size());
+            std::iota(s.order.begin(), s.order.end(), 0);
+            std::stable_sort(s.order.begin(), s.order.end(),
+                             [&](int p, int q) {
+                                 return s.vel[p] < s.vel[q];
+                             });
         }
         const size_t m = s.cand.size();
-        s.order.resize(m);
-        std::iota(s.order.begin(), s.order.end(), 0);
-        std::stable_sort(s.order.begin(), s.order.end(), [&](int p, int q) {
-            return s.vel[p] < s.vel[q];
-        });
         int *out = m ? s.pool_alloc(m) : nullptr;
         for (size_t k = 0; k < m; ++k) out[k] = s.cand[(size_t)s.order[k]];
         nb_ptr_[(size_t)i] = out;
@@ -730,6 +781,9 @@ private:
     hk_clip &c_;
     const int n_;
     std::vector<int> queue_, qpos_;     // seeds top of the frame first
+    std::vector<int> xs_idx_;           // tags by (frame, x)
+    std::vector<double> xs_val_;        // their x
+    bool x_index_ok_ = false;
     std::vector<const int *> nb_ptr_;
     std::vector<int> nb_len_;
     std::unique_ptr<std::atomic<uint8_t>[]> nb_state_;
