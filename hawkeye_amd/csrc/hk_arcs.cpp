@@ -216,9 +216,24 @@ public:
           nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           done_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           done_at_((size_t)c.n, -1) {
-        std::iota(queue_.begin(), queue_.end(), 0);
-        std::stable_sort(queue_.begin(), queue_.end(),
-                         [&](int p, int q) { return c.y[p] < c.y[q]; });
+        {   // top of the frame first; equal heights keep their tag order
+            std::vector<std::pair<double, int>> keyed((size_t)c.n);
+            for (int i = 0; i < c.n; ++i) keyed[(size_t)i] = {c.y[i], i};
+            bool finite = true;
+            for (int i = 0; i < c.n && finite; ++i)
+                finite = !std::isnan(c.y[i]);
+            if (finite) {
+                std::sort(keyed.begin(), keyed.end());
+            } else {            // NaN keys: only a stable sort is defined
+                std::stable_sort(keyed.begin(), keyed.end(),
+                                 [](const std::pair<double, int> &p,
+                                    const std::pair<double, int> &q) {
+                                     return p.first < q.first;
+                                 });
+            }
+            for (int k = 0; k < c.n; ++k)
+                queue_[(size_t)k] = keyed[(size_t)k].second;
+        }
         for (int k = 0; k < n_; ++k) qpos_[(size_t)queue_[(size_t)k]] = k;
         // per frame, the tags ordered by x (for the neighbour search)
         xs_idx_.resize((size_t)c.n);
