@@ -57,6 +57,7 @@ _sig('hk_set_host_threads', [C.c_int])
 _sig('hk_set_self_check', [C.c_int])
 
 _sig('hk_mog_create', [C.c_int, C.c_int, C.c_int, c_void_pp])
+_sig('hk_mog_selfcheck_math', [C.c_int, C.POINTER(C.c_longlong)])
 _sig('hk_mog_destroy', [C.c_void_p])
 _sig('hk_mog_reset', [C.c_void_p, C.c_void_p])
 _sig('hk_mog_nframes', [C.c_void_p])

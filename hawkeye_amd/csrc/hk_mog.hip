@@ -20,6 +20,8 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "hk_common.h"
@@ -40,14 +42,53 @@ struct MogConst {
 struct Mix {                // one pixel's mixture, lives in VGPRs
     float f[8][K];          // [field][component]; every index is a
                             // compile-time constant after unrolling
+    __device__ __forceinline__ float get(int q, int k) const { return f[q][k]; }
+    __device__ __forceinline__ void set(int q, int k, float v) { f[q][k] = v; }
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Two neighbouring pixels: .x and .y of every value sit in an aligned VGPR
+// pair (v_pk_* ops).  Only what every frame touches lives in registers: all
+// weights and sort keys, and the mean / variance of components 0 and 1.  The
+// mean / variance of components 2-4 ("cold": read only when a pixel leaves
+// its first two modes) live in LDS, 18 values x 2 pixels per thread, so that
+// the kernel fits 128 VGPRs without spilling to scratch.
+constexpr int COLD_FROM = 2;
+constexpr int N_COLD = 6 * (K - COLD_FROM);         // 18
+__device__ __forceinline__ constexpr bool is_cold(int q, int k) {
+    return k >= COLD_FROM && q >= F_M0;
+}
+__device__ __forceinline__ constexpr int cold_slot(int q, int k) {
+    return ((q - F_M0) * (K - COLD_FROM) + (k - COLD_FROM)) * 512;
+}
+
+struct Mix2 {
+    f2 f[8][K];             // cold entries are never touched (dead registers)
+    float *cold;            // this thread's LDS base: cold[slot + pixel]
+};
+
+template <int L>
+struct Lane {               // one pixel of a Mix2, seen as a Mix
+    Mix2 &m;
+    __device__ __forceinline__ float get(int q, int k) const {
+        if (is_cold(q, k)) return m.cold[cold_slot(q, k) + L];
+        return L ? m.f[q][k].y : m.f[q][k].x;
+    }
+    __device__ __forceinline__ void set(int q, int k, float v) {
+        if (is_cold(q, k)) m.cold[cold_slot(q, k) + L] = v;
+        else if (L) m.f[q][k].y = v;
+        else m.f[q][k].x = v;
+    }
 };
 
 __device__ __forceinline__ float max_like_std(float a, float b) {
     return (a < b) ? b : a;             // std::max(a, b)
 }
 
-// One frame of one pixel.  Returns 255 (foreground) or 0.
-__device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
+// One frame of one pixel, the general case.  Returns 255 (foreground) or 0.
+template <class P>
+__device__ __forceinline__ unsigned mog_step(P &p, float x0, float x1,
                                              float x2, float alpha,
                                              const MogConst c) {
     float wsum = 0.f;
@@ -58,33 +99,34 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (scanning) {
-            const float w = p.f[F_W][k];
+            const float w = p.get(F_W, k);
             wsum += w;
             if (w < FLT_EPSILON) {
                 scanning = false;
                 kEnd = k;
             } else {
-                const float d0 = x0 - p.f[F_M0][k];
-                const float d1 = x1 - p.f[F_M1][k];
-                const float d2 = x2 - p.f[F_M2][k];
-                float v0 = p.f[F_V0][k], v1 = p.f[F_V1][k], v2 = p.f[F_V2][k];
+                const float d0 = x0 - p.get(F_M0, k);
+                const float d1 = x1 - p.get(F_M1, k);
+                const float d2 = x2 - p.get(F_M2, k);
+                float v0 = p.get(F_V0, k), v1 = p.get(F_V1, k),
+                      v2 = p.get(F_V2, k);
                 float dist2 = d0 * d0;
                 dist2 = dist2 + d1 * d1;
                 dist2 = dist2 + d2 * d2;
                 if (dist2 < c.vT * (v0 + v1 + v2)) {
                     wsum -= w;
                     const float dw = alpha * (1.f - w);
-                    p.f[F_W][k] = w + dw;
-                    p.f[F_M0][k] = p.f[F_M0][k] + alpha * d0;
-                    p.f[F_M1][k] = p.f[F_M1][k] + alpha * d1;
-                    p.f[F_M2][k] = p.f[F_M2][k] + alpha * d2;
+                    p.set(F_W, k, w + dw);
+                    p.set(F_M0, k, p.get(F_M0, k) + alpha * d0);
+                    p.set(F_M1, k, p.get(F_M1, k) + alpha * d1);
+                    p.set(F_M2, k, p.get(F_M2, k) + alpha * d2);
                     v0 = max_like_std(v0 + alpha * (d0 * d0 - v0), c.minVar);
                     v1 = max_like_std(v1 + alpha * (d1 * d1 - v1), c.minVar);
                     v2 = max_like_std(v2 + alpha * (d2 * d2 - v2), c.minVar);
-                    p.f[F_V0][k] = v0;
-                    p.f[F_V1][k] = v1;
-                    p.f[F_V2][k] = v2;
-                    p.f[F_SK][k] = w / sqrtf(v0 + v1 + v2);
+                    p.set(F_V0, k, v0);
+                    p.set(F_V1, k, v1);
+                    p.set(F_V2, k, v2);
+                    p.set(F_SK, k, w / sqrtf(v0 + v1 + v2));
 
                     // keep components ordered by sortKey (insertion step)
                     int pos = k;
@@ -92,14 +134,14 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
 #pragma unroll
                     for (int k1 = k - 1; k1 >= 0; --k1) {
                         if (moving) {
-                            if (p.f[F_SK][k1] >= p.f[F_SK][k1 + 1]) {
+                            if (p.get(F_SK, k1) >= p.get(F_SK, k1 + 1)) {
                                 moving = false;
                             } else {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) {
-                                    const float t = p.f[q][k1];
-                                    p.f[q][k1] = p.f[q][k1 + 1];
-                                    p.f[q][k1 + 1] = t;
+                                    const float t = p.get(q, k1);
+                                    p.set(q, k1, p.get(q, k1 + 1));
+                                    p.set(q, k1 + 1, t);
                                 }
                                 pos = k1;
                             }
@@ -109,7 +151,7 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
                     // upstream adds the tail from index k of the REORDERED
                     // array; reproduced as is
 #pragma unroll
-                    for (int kk = k; kk < K; ++kk) wsum += p.f[F_W][kk];
+                    for (int kk = k; kk < K; ++kk) wsum += p.get(F_W, kk);
                     scanning = false;
                     kEnd = k;
                 }
@@ -123,15 +165,15 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             if (kk == kr) {
-                wsum += c.w0 - p.f[F_W][kk];
-                p.f[F_W][kk] = c.w0;
-                p.f[F_M0][kk] = x0;
-                p.f[F_M1][kk] = x1;
-                p.f[F_M2][kk] = x2;
-                p.f[F_V0][kk] = c.var0;
-                p.f[F_V1][kk] = c.var0;
-                p.f[F_V2][kk] = c.var0;
-                p.f[F_SK][kk] = c.sk0;
+                wsum += c.w0 - p.get(F_W, kk);
+                p.set(F_W, kk, c.w0);
+                p.set(F_M0, kk, x0);
+                p.set(F_M1, kk, x1);
+                p.set(F_M2, kk, x2);
+                p.set(F_V0, kk, c.var0);
+                p.set(F_V1, kk, c.var0);
+                p.set(F_V2, kk, c.var0);
+                p.set(F_SK, kk, c.sk0);
             }
         }
     }
@@ -141,12 +183,179 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
     int kFg = -1;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        p.f[F_W][k] *= wscale;
-        wsum += p.f[F_W][k];
-        p.f[F_SK][k] *= wscale;
+        p.set(F_W, k, p.get(F_W, k) * wscale);
+        wsum += p.get(F_W, k);
+        p.set(F_SK, k, p.get(F_SK, k) * wscale);
         if (wsum > c.T && kFg < 0) kFg = k + 1;
     }
     return (kHit >= kFg) ? 255u : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// The common case -- both pixels of a lane match their component 0 (the
+// background mode) -- in packed fp32: every add/mul/fma handles the two pixels
+// at once.  Same operations in the same order as mog_step, with these
+// value-preserving shortcuts (the operands' ranges are known here):
+//  * k == 0: wsum = ((0 + w) - w) + W0' + W1.. = W0' + W1.. exactly;
+//  * sqrt / divide: the compiler's correctly rounded sequences minus their
+//    range scaling and special-case fix-ups, which are the identity for
+//    12.9 <= sqrt argument <= 2e5, FLT_EPSILON <= w <= 1, 2^-23 <= wsum <= 8
+//    (hk_mog_selfcheck_math compares them with the IEEE operators over these
+//    ranges);
+//  * max(v, minVar) as v_max_f32 (v is never NaN);
+//  * kHit == 0: foreground iff the weights never sum past T (cumulative sums
+//    of non-negative weights are monotone, so kHit >= kFg reduces to that).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+// correctly rounded sqrt for normal x with no range scaling needed
+__device__ __forceinline__ float sqrt_ranged(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    float r = (0.f >= rm) ? sm : s;
+    r = (0.f < rp) ? sp : r;
+    return r;
+}
+
+__device__ __forceinline__ f2 sqrt_ranged2(f2 x) {
+    f2 s, sm, sp;
+    s.x = __builtin_amdgcn_sqrtf(x.x);
+    s.y = __builtin_amdgcn_sqrtf(x.y);
+    sm.x = __int_as_float(__float_as_int(s.x) - 1);
+    sm.y = __int_as_float(__float_as_int(s.y) - 1);
+    sp.x = __int_as_float(__float_as_int(s.x) + 1);
+    sp.y = __int_as_float(__float_as_int(s.y) + 1);
+    const f2 rm = fma2(-sm, s, x);
+    const f2 rp = fma2(-sp, s, x);
+    f2 r;
+    r.x = (0.f >= rm.x) ? sm.x : s.x;
+    r.y = (0.f >= rm.y) ? sm.y : s.y;
+    r.x = (0.f < rp.x) ? sp.x : r.x;
+    r.y = (0.f < rp.y) ? sp.y : r.y;
+    return r;
+}
+
+// correctly rounded n / d when no operand or intermediate needs scaling
+__device__ __forceinline__ float div_ranged(float n, float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.f);
+    const float r = __builtin_fmaf(e0, r0, r0);
+    const float q0 = n * r;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r, q1);
+}
+
+__device__ __forceinline__ f2 div_ranged2(f2 n, f2 d) {
+    f2 r0;
+    r0.x = __builtin_amdgcn_rcpf(d.x);
+    r0.y = __builtin_amdgcn_rcpf(d.y);
+    const f2 one = {1.f, 1.f};
+    const f2 e0 = fma2(-d, r0, one);
+    const f2 r = fma2(e0, r0, r0);
+    const f2 q0 = n * r;
+    const f2 e1 = fma2(-d, q0, n);
+    const f2 q1 = fma2(e1, r, q0);
+    const f2 e2 = fma2(-d, q1, n);
+    return fma2(e2, r, q1);
+}
+
+// sortKey of component 0, deferred.  A fast step would set
+//     SK[0] = (w_old / sqrt(var sum)) * wscale,
+// a value nothing reads if the next frame takes the fast step again (it is
+// overwritten from scratch).  So the fast step only notes the three operands;
+// the square root, the division and the product are done when the value is
+// needed: before a general step of this lane, and before the model is stored.
+struct LazySK {
+    f2 w, s, scale;         // s == 0: SK[0] in the model is current
+};
+
+__device__ __forceinline__ void materialise_sk0(Mix2 &p, LazySK &z) {
+    const bool sx = z.s.x != 0.f, sy = z.s.y != 0.f;
+    f2 s;
+    s.x = sx ? z.s.x : 1024.f;
+    s.y = sy ? z.s.y : 1024.f;
+    f2 w;
+    w.x = sx ? z.w.x : 1.f;
+    w.y = sy ? z.w.y : 1.f;
+    const f2 sk = div_ranged2(w, sqrt_ranged2(s)) * z.scale;
+    p.f[F_SK][0].x = sx ? sk.x : p.f[F_SK][0].x;
+    p.f[F_SK][0].y = sy ? sk.y : p.f[F_SK][0].y;
+    z.s.x = 0.f;
+    z.s.y = 0.f;
+}
+
+// Both pixels of `p` against their component 0.  Returns true and the 16-bit
+// mask pair if both matched (model updated, SK[0] deferred into `z`); false
+// with `p` untouched if either did not.
+__device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
+                                               f2 x1, f2 x2, float alpha,
+                                               const MogConst c,
+                                               unsigned &mask) {
+    const f2 w = p.f[F_W][0];
+    const f2 d0 = x0 - p.f[F_M0][0];
+    const f2 d1 = x1 - p.f[F_M1][0];
+    const f2 d2 = x2 - p.f[F_M2][0];
+    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
+    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    f2 dist2 = q0 + q1;
+    dist2 = dist2 + q2;
+    const f2 thr = c.vT * ((v0 + v1) + v2);
+    const bool hit = !(w.x < FLT_EPSILON) && !(w.y < FLT_EPSILON) &&
+                     dist2.x < thr.x && dist2.y < thr.y;
+    if (!hit) return false;
+
+    const f2 one = {1.f, 1.f};
+    const f2 wn = w + alpha * (one - w);
+    f2 wsum = wn + p.f[F_W][1];
+#pragma unroll
+    for (int k = 2; k < K; ++k) wsum = wsum + p.f[F_W][k];
+    // 1 / wsum: its dependent fma chain is interleaved by hand with the
+    // independent mean / variance updates (same operations, same operands)
+    f2 r0;
+    r0.x = __builtin_amdgcn_rcpf(wsum.x);
+    r0.y = __builtin_amdgcn_rcpf(wsum.y);
+    p.f[F_M0][0] = p.f[F_M0][0] + alpha * d0;
+    const f2 e0 = fma2(-wsum, r0, one);
+    p.f[F_M1][0] = p.f[F_M1][0] + alpha * d1;
+    const f2 r = fma2(e0, r0, r0);
+    p.f[F_M2][0] = p.f[F_M2][0] + alpha * d2;
+    const f2 e1 = fma2(-wsum, r, one);          // q0 = 1 * r = r
+    v0 = v0 + alpha * (q0 - v0);
+    const f2 q1r = fma2(e1, r, r);
+    v1 = v1 + alpha * (q1 - v1);
+    const f2 e2 = fma2(-wsum, q1r, one);
+    v2 = v2 + alpha * (q2 - v2);
+    const f2 wscale = fma2(e2, r, q1r);
+    v0.x = __builtin_fmaxf(v0.x, c.minVar);
+    v0.y = __builtin_fmaxf(v0.y, c.minVar);
+    v1.x = __builtin_fmaxf(v1.x, c.minVar);
+    v1.y = __builtin_fmaxf(v1.y, c.minVar);
+    v2.x = __builtin_fmaxf(v2.x, c.minVar);
+    v2.y = __builtin_fmaxf(v2.y, c.minVar);
+    p.f[F_V0][0] = v0;
+    p.f[F_V1][0] = v1;
+    p.f[F_V2][0] = v2;
+    z.w = w;
+    z.s = (v0 + v1) + v2;
+    z.scale = wscale;
+
+    p.f[F_W][0] = wn * wscale;
+    f2 cum = p.f[F_W][0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        p.f[F_W][k] = p.f[F_W][k] * wscale;
+        cum = cum + p.f[F_W][k];
+        p.f[F_SK][k] = p.f[F_SK][k] * wscale;
+    }
+    mask = (cum.x > c.T ? 0u : 255u) | (cum.y > c.T ? 0u : 255u << 8);
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -162,68 +371,149 @@ __device__ __forceinline__ unsigned mog_step(Mix &p, float x0, float x1,
 // batches.  WAVES = 2 (no spills) is best when a launch is a single frame and
 // the 320 B/pixel of model traffic dominate.
 // ---------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, int DEPTH, bool TILED>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
-    float *__restrict__ planes, long n_pixels, const uint8_t *__restrict__ bgr,
+    float *__restrict__ planes, long n_pixels, int width,
+    const uint8_t *__restrict__ bgr,
     long bgr_frame_stride, uint8_t *__restrict__ mask, long mask_frame_stride,
     int nframes, int frames_before, const float *__restrict__ alpha_table,
     const MogConst c) {
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;    // pair
-    const long i0 = g * 2;
+    long i0 = g * 2;
     if (i0 >= n_pixels) return;
+    if (TILED) {
+        // A wave owns a 32 x 4 pixel tile instead of a 128-pixel run of a
+        // row: pixels off the fast path come in compact 2-D groups (moving
+        // objects, their edges), which then touch ~3x fewer waves.
+        // Requires width % 32 == 0 and height % 4 == 0.
+        const int lane = threadIdx.x & 63;
+        const long tile = g >> 6;
+        const int tiles_x = width >> 5;
+        const long ty = tile / tiles_x;
+        const int tx = (int)(tile - ty * tiles_x);
+        i0 = (ty * 4 + (lane >> 4)) * width + tx * 32 + (lane & 15) * 2;
+    }
 
-    Mix px[2];
+    // A component that was never created has weight 0 and all-zero fields
+    // (the model starts zeroed, components are created with weight w0 > 0 and
+    // weights are only ever rescaled), so its planes are neither read nor
+    // written back: most pixels have one or two modes.
+    __shared__ float cold_lds[N_COLD * 512];
+    Mix2 px;
+    px.cold = cold_lds + threadIdx.x * 2;
+    float *const base = planes + i0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int k = 0; k < K; ++k) {
+        const float2 w = *reinterpret_cast<const float2 *>(
+            base + (long)(F_W * K + k) * n_pixels);
+        px.f[F_W][k].x = w.x;
+        px.f[F_W][k].y = w.y;
+    }
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float2 v = *reinterpret_cast<const float2 *>(
-                planes + (long)(q * K + k) * n_pixels + i0);
-            px[0].f[q][k] = v.x;
-            px[1].f[q][k] = v.y;
+    for (int k = 0; k < K; ++k) {
+        const bool used = k == 0 || px.f[F_W][k].x != 0.f ||
+                          px.f[F_W][k].y != 0.f;
+#pragma unroll
+        for (int q = F_SK; q < 8; ++q) {
+            float2 v = make_float2(0.f, 0.f);
+            if (used)
+                v = *reinterpret_cast<const float2 *>(
+                    base + (long)(q * K + k) * n_pixels);
+            if (is_cold(q, k)) {    // zeros too: one pixel of the pair may
+                px.cold[cold_slot(q, k)] = v.x;         // create the component
+                px.cold[cold_slot(q, k) + 1] = v.y;     // and both are stored
+            } else {
+                px.f[q][k].x = v.x;
+                px.f[q][k].y = v.y;
+            }
         }
     }
 
+    LazySK lazy;
+    lazy.w = lazy.s = lazy.scale = f2{0.f, 0.f};
+
+    // The 6 input bytes of a frame are far from those of the next frame, so
+    // every load is an HBM miss (~2 us under load): the frames of the next
+    // group of DEPTH are requested while this group is processed.
     const uint8_t *src = bgr + i0 * 3;
     uint8_t *dst = mask + i0;
-    const unsigned short *s16 = reinterpret_cast<const unsigned short *>(src);
-    unsigned c0 = s16[0], c1 = s16[1], c2 = s16[2];
-    for (int t = 0; t < nframes; ++t) {
-        unsigned n0 = c0, n1 = c1, n2 = c2;
-        if (t + 1 < nframes) {          // next frame's bytes, ahead of use
-            const unsigned short *nx = reinterpret_cast<const unsigned short *>(
-                src + (long)(t + 1) * bgr_frame_stride);
-            n0 = nx[0];
-            n1 = nx[1];
-            n2 = nx[2];
+    unsigned cur[DEPTH][2], nxt[DEPTH][3];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+        const int f = j < nframes ? j : nframes - 1;
+        const unsigned short *s16 = reinterpret_cast<const unsigned short *>(
+            src + (long)f * bgr_frame_stride);
+        cur[j][0] = s16[0] | ((unsigned)s16[1] << 16);
+        cur[j][1] = s16[2];
+    }
+    for (int t0 = 0; t0 < nframes; t0 += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            int f = t0 + DEPTH + j;
+            f = f < nframes ? f : nframes - 1;
+            const unsigned short *s16 = reinterpret_cast<const unsigned short *>(
+                src + (long)f * bgr_frame_stride);
+            nxt[j][0] = s16[0];
+            nxt[j][1] = s16[1];
+            nxt[j][2] = s16[2];
         }
-        int n = frames_before + t + 1;
-        n = n < HISTORY ? n : HISTORY;
-        const float alpha = alpha_table[n - 1];
-
-        // bytes b0 g0 | r0 b1 | g1 r1
-        unsigned m;
-        m = mog_step(px[0], (float)(c0 & 255u), (float)(c0 >> 8),
-                     (float)(c1 & 255u), alpha, c);
-        m |= mog_step(px[1], (float)(c1 >> 8), (float)(c2 & 255u),
-                      (float)(c2 >> 8), alpha, c) << 8;
-        *reinterpret_cast<unsigned short *>(dst + (long)t * mask_frame_stride) =
-            (unsigned short)m;
-        c0 = n0;
-        c1 = n1;
-        c2 = n2;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int t = t0 + j;
+            if (t < nframes) {
+                int n = frames_before + t + 1;
+                n = n < HISTORY ? n : HISTORY;
+                const float alpha = alpha_table[n - 1];
+                const unsigned c01 = cur[j][0], c2 = cur[j][1];
+                // bytes b0 g0 | r0 b1 | g1 r1
+                f2 x0, x1, x2;
+                x0.x = (float)(c01 & 255u);
+                x1.x = (float)((c01 >> 8) & 255u);
+                x2.x = (float)((c01 >> 16) & 255u);
+                x0.y = (float)(c01 >> 24);
+                x1.y = (float)(c2 & 255u);
+                x2.y = (float)(c2 >> 8);
+                unsigned m;
+                if (!mog_step_pair0(px, lazy, x0, x1, x2, alpha, c, m)) {
+                    materialise_sk0(px, lazy);
+                    Lane<0> l0{px};
+                    Lane<1> l1{px};
+                    m = mog_step(l0, x0.x, x1.x, x2.x, alpha, c);
+                    m |= mog_step(l1, x0.y, x1.y, x2.y, alpha, c) << 8;
+                }
+                *reinterpret_cast<unsigned short *>(
+                    dst + (long)t * mask_frame_stride) = (unsigned short)m;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            cur[j][0] = nxt[j][0] | (nxt[j][1] << 16);
+            cur[j][1] = nxt[j][2];
+        }
     }
 
+    materialise_sk0(px, lazy);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int k = 0; k < K; ++k) {
+        *reinterpret_cast<float2 *>(base + (long)(F_W * K + k) * n_pixels) =
+            make_float2(px.f[F_W][k].x, px.f[F_W][k].y);
+        const bool used = k == 0 || px.f[F_W][k].x != 0.f ||
+                          px.f[F_W][k].y != 0.f;
+        if (used) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float2 v;
-            v.x = px[0].f[q][k];
-            v.y = px[1].f[q][k];
-            *reinterpret_cast<float2 *>(planes + (long)(q * K + k) * n_pixels +
-                                        i0) = v;
+            for (int q = F_SK; q < 8; ++q) {
+                float2 v;
+                if (is_cold(q, k)) {
+                    v.x = px.cold[cold_slot(q, k)];
+                    v.y = px.cold[cold_slot(q, k) + 1];
+                } else {
+                    v.x = px.f[q][k].x;
+                    v.y = px.f[q][k].y;
+                }
+                *reinterpret_cast<float2 *>(
+                    base + (long)(q * K + k) * n_pixels) = v;
+            }
         }
     }
 }
@@ -265,6 +555,56 @@ __global__ __launch_bounds__(256) void mog_batch1_k(
 #pragma unroll
         for (int k = 0; k < K; ++k)
             planes[(long)(q * K + k) * n_pixels + i] = px.f[q][k];
+}
+
+// ---------------------------------------------------------------------------
+// Self-check of the trimmed sqrt / divide sequences against the IEEE
+// operators (which this file is compiled to round correctly) over the ranges
+// the packed path uses them on, and wider.
+//   part 0: sqrt_ranged(x)      for every float in [2, 2^22)
+//   part 1: div_ranged(1, x)    for every float in [2^-26, 2^6)
+//   part 2: div_ranged(n, d)    n in [2^-26, 4), d in [1, 2^12), hashed samples
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void mog_math_check_k(
+    int part, unsigned lo_bits, unsigned long long count,
+    unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x +
+                                threadIdx.x; i < count; i += stride) {
+        if (part == 0) {
+            const float x = __uint_as_float(lo_bits + (unsigned)i);
+            bad += __float_as_uint(sqrt_ranged(x)) != __float_as_uint(sqrtf(x));
+        } else if (part == 1) {
+            const float x = __uint_as_float(lo_bits + (unsigned)i);
+            bad += __float_as_uint(div_ranged(1.f, x)) !=
+                   __float_as_uint(1.f / x);
+        } else {
+            const unsigned h0 = mix32((unsigned)i * 2u + 1u);
+            const unsigned h1 = mix32(h0 ^ (unsigned)(i >> 32) ^ 0x9e3779b9u);
+            // n: exponent 2^-26 .. 2^1, d: exponent 2^0 .. 2^11
+            const unsigned ne = 101u + (h0 >> 23) % 28u;
+            const unsigned de = 127u + (h1 >> 23) % 12u;
+            const float n = __uint_as_float((ne << 23) | (h0 & 0x7fffffu));
+            const float d = __uint_as_float((de << 23) | (h1 & 0x7fffffu));
+            bad += __float_as_uint(div_ranged(n, d)) != __float_as_uint(n / d);
+            f2 n2 = {n, d}, d2 = {d, n + 1.f};
+            const f2 q = div_ranged2(n2, d2);
+            bad += __float_as_uint(q.x) != __float_as_uint(n / d);
+            bad += __float_as_uint(q.y) != __float_as_uint(d / (n + 1.f));
+            f2 s2 = {d, d * 3.f};
+            const f2 r = sqrt_ranged2(s2);
+            bad += __float_as_uint(r.x) != __float_as_uint(sqrtf(d));
+            bad += __float_as_uint(r.y) != __float_as_uint(sqrtf(d * 3.f));
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 }  // namespace
@@ -376,19 +716,29 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
         const long pairs = N / 2;
         const unsigned blocks = (unsigned)((pairs + 255) / 256);
         // short launches stream the model (HBM-bound), long ones are
-        // arithmetic-bound: see mog_batch2_k
-        if (nframes <= 4)
-            hipLaunchKernelGGL(mog_batch2_k<2>, dim3(blocks), dim3(256), 0, s,
-                               m->planes, N, (const uint8_t *)bgr_dev,
-                               bgr_frame_stride, (uint8_t *)mask_dev,
-                               mask_frame_stride, nframes, m->nframes,
-                               m->alpha_table, m->c);
-        else
-            hipLaunchKernelGGL(mog_batch2_k<4>, dim3(blocks), dim3(256), 0, s,
-                               m->planes, N, (const uint8_t *)bgr_dev,
-                               bgr_frame_stride, (uint8_t *)mask_dev,
-                               mask_frame_stride, nframes, m->nframes,
-                               m->alpha_table, m->c);
+        // bound by the latency of the frame loads and by arithmetic: see
+        // mog_batch2_k
+#define HK_MOG_LAUNCH(W, D, TL)                                               \
+        hipLaunchKernelGGL((mog_batch2_k<W, D, TL>), dim3(blocks), dim3(256), \
+                           0, s, m->planes, N, m->width,                      \
+                           (const uint8_t *)bgr_dev,                          \
+                           bgr_frame_stride, (uint8_t *)mask_dev,             \
+                           mask_frame_stride, nframes, m->nframes,            \
+                           m->alpha_table, m->c)
+        static const int variant = [] {
+            const char *e = getenv("HK_MOG_VARIANT");
+            return e ? atoi(e) : 0;
+        }();
+        const bool tileable = m->width % 32 == 0 && m->height % 4 == 0;
+        if (nframes <= 4 && variant != 7) HK_MOG_LAUNCH(2, 1, false);
+        else if (nframes <= 4) HK_MOG_LAUNCH(4, 1, false);
+        else if (variant == 1) HK_MOG_LAUNCH(4, 2, false);
+        else if (variant == 2 || !tileable) HK_MOG_LAUNCH(4, 4, false);
+        else if (variant == 3) HK_MOG_LAUNCH(4, 2, true);
+        else if (variant == 5) HK_MOG_LAUNCH(4, 8, true);
+        else if (variant == 6) HK_MOG_LAUNCH(4, 1, false);
+        else HK_MOG_LAUNCH(4, 4, true);
+#undef HK_MOG_LAUNCH
         HK_LAUNCH_CHECK("mog_batch2_k");
     } else {
         const unsigned blocks = (unsigned)((N + 255) / 256);
@@ -426,5 +776,39 @@ extern "C" int hk_mog_export_model(hk_mog *m, float *host_out, void *stream) {
             for (int j = 0; j < 8; ++j)
                 host_out[(i * K + k) * 8 + j] =
                     soa[(size_t)(aos_field[j] * K + k) * N + i];
+    return HK_OK;
+}
+
+extern "C" int hk_mog_selfcheck_math(int device, long long *mismatches_out) {
+    if (!mismatches_out)
+        return hk::fail(HK_ERR_ARG, "hk_mog_selfcheck_math: null argument");
+    hk::DeviceGuard guard(device);
+    if (!guard.ok)
+        return hk::fail(HK_ERR_HIP,
+                        "hk_mog_selfcheck_math: cannot select device %d",
+                        device);
+    unsigned long long *d_bad = nullptr;
+    HK_HIP(hipMalloc((void **)&d_bad, sizeof(*d_bad)));
+    hipError_t e = hipMemset(d_bad, 0, sizeof(*d_bad));
+    auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+    const struct { int part; unsigned lo; unsigned long long n; } runs[3] = {
+        {0, bits(2.f), (unsigned long long)bits(4194304.f) - bits(2.f)},
+        {1, bits(1.4901161e-8f), (unsigned long long)bits(64.f) -
+                                     bits(1.4901161e-8f)},
+        {2, 0u, 1ull << 30},
+    };
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+        hipLaunchKernelGGL(mog_math_check_k, dim3(256 * 32), dim3(256), 0, 0,
+                           runs[i].part, runs[i].lo, runs[i].n, d_bad);
+        e = hipGetLastError();
+    }
+    unsigned long long bad = 0;
+    if (e == hipSuccess)
+        e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess)
+        return hk::fail(HK_ERR_HIP, "hk_mog_selfcheck_math: %s",
+                        hipGetErrorString(e));
+    *mismatches_out = (long long)bad;
     return HK_OK;
 }

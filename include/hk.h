@@ -87,6 +87,14 @@ int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
  * (sortKey, weight, mean[3], var[3]).  For tests.  Synchronises. */
 int hk_mog_export_model(hk_mog *m, float *host_out, void *stream);
 
+/* The packed fast path of the batch kernel replaces the IEEE square root and
+ * divisions of process8uC3 by the same correctly rounded sequences without
+ * their range scaling (operand ranges are known there).  This compares them
+ * with the IEEE operators exhaustively over those ranges on `device` and
+ * returns the number of differing results (must be 0).  For tests.
+ * Synchronises. */
+int hk_mog_selfcheck_math(int device, long long *mismatches_out);
+
 /* ------------------------------------------------------------------------
  * K2-K4  blob detection on binary masks
  *     replaces cv2.SimpleBlobDetector_create(params).detect(fgmask)

@@ -137,3 +137,12 @@ def test_full_hd_round_trip_properties():
     b = BackgroundSubtractorMOG(w, h)
     for i in range(6):
         assert torch.equal(b.apply(frames[i]), masks[i])
+
+
+def test_trimmed_sqrt_and_divide_equal_ieee_over_their_ranges():
+    """The packed fast path's sqrt / divide sequences against the IEEE
+    operators: exhaustive over the operand ranges (hk_mog_selfcheck_math)."""
+    from hawkeye_amd import _native as nat
+    bad = nat.C.c_longlong(-1)
+    nat.check(nat.lib.hk_mog_selfcheck_math(0, nat.C.byref(bad)))
+    assert bad.value == 0
