@@ -60,7 +60,7 @@ __device__ __forceinline__ constexpr bool is_cold(int q, int k) {
     return k >= COLD_FROM && q >= F_M0;
 }
 __device__ __forceinline__ constexpr int cold_slot(int q, int k) {
-    return ((q - F_M0) * (K - COLD_FROM) + (k - COLD_FROM)) * 512;
+    return ((q - F_M0) * (K - COLD_FROM) + (k - COLD_FROM)) * 128;
 }
 
 struct Mix2 {
@@ -371,15 +371,31 @@ __device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
 // batches.  WAVES = 2 (no spills) is best when a launch is a single frame and
 // the 320 B/pixel of model traffic dominate.
 // ---------------------------------------------------------------------------
+#ifdef HK_MOG_TRACE
+__device__ unsigned long long *g_trace = nullptr;   // scratch probe only
+#endif
+
 template <int WAVES, int DEPTH, bool TILED>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     float *__restrict__ planes, long n_pixels, int width,
     const uint8_t *__restrict__ bgr,
     long bgr_frame_stride, uint8_t *__restrict__ mask, long mask_frame_stride,
     int nframes, int frames_before, const float *__restrict__ alpha_table,
-    const MogConst c) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;    // pair
+    const MogConst c, int n_groups, const int *__restrict__ order,
+    int *__restrict__ cost) {
+    // One wave per workgroup, so that a finished wave's slot and LDS are
+    // reused at once (waves of one workgroup end at very different times).
+    // A "group" is 4 units of 128 pixels that share cache lines of the frame
+    // rows; workgroups go to the 8 XCDs round-robin by index, so the 4 units
+    // of a group take indices 8 apart and meet in one XCD's L2.  `order`
+    // (may be null) lists the groups, slowest of the previous launch first:
+    // see mog_order_k.
+    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const unsigned pos = (j >> 2) * 8 + xcd;
+    if (pos >= (unsigned)n_groups) return;
+    const unsigned group = order ? (unsigned)order[pos] : pos;
+    const long g = ((long)group * 4 + (j & 3)) * 64 + threadIdx.x;  // pair
     long i0 = g * 2;
     if (i0 >= n_pixels) return;
     if (TILED) {
@@ -387,7 +403,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
         // row: pixels off the fast path come in compact 2-D groups (moving
         // objects, their edges), which then touch ~3x fewer waves.
         // Requires width % 32 == 0 and height % 4 == 0.
-        const int lane = threadIdx.x & 63;
+        const int lane = threadIdx.x;
         const long tile = g >> 6;
         const int tiles_x = width >> 5;
         const long ty = tile / tiles_x;
@@ -399,7 +415,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     // (the model starts zeroed, components are created with weight w0 > 0 and
     // weights are only ever rescaled), so its planes are neither read nor
     // written back: most pixels have one or two modes.
-    __shared__ float cold_lds[N_COLD * 512];
+    __shared__ float cold_lds[N_COLD * 128];
     Mix2 px;
     px.cold = cold_lds + threadIdx.x * 2;
     float *const base = planes + i0;
@@ -432,6 +448,10 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 
     LazySK lazy;
     lazy.w = lazy.s = lazy.scale = f2{0.f, 0.f};
+    int slow_steps = 0;     // frames in which this wave left the fast step
+#ifdef HK_MOG_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // The 6 input bytes of a frame are far from those of the next frame, so
     // every load is an HBM miss (~2 us under load): the frames of the next
@@ -475,12 +495,19 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                 x1.y = (float)(c2 & 255u);
                 x2.y = (float)(c2 >> 8);
                 unsigned m;
-                if (!mog_step_pair0(px, lazy, x0, x1, x2, alpha, c, m)) {
+                const bool fast = mog_step_pair0(px, lazy, x0, x1, x2, alpha,
+                                                 c, m);
+                slow_steps += __builtin_amdgcn_ballot_w64(!fast) != 0;
+                if (!fast) {
+                    // the launch ends when its slowest wave does: waves in
+                    // the long general step go first at instruction issue
+                    __builtin_amdgcn_s_setprio(3);
                     materialise_sk0(px, lazy);
                     Lane<0> l0{px};
                     Lane<1> l1{px};
                     m = mog_step(l0, x0.x, x1.x, x2.x, alpha, c);
                     m |= mog_step(l1, x0.y, x1.y, x2.y, alpha, c) << 8;
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 *reinterpret_cast<unsigned short *>(
                     dst + (long)t * mask_frame_stride) = (unsigned short)m;
@@ -493,6 +520,17 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
         }
     }
 
+    if (cost && threadIdx.x == 0 && slow_steps)
+        atomicMax(&cost[group], slow_steps);
+#ifdef HK_MOG_TRACE
+    if (g_trace && threadIdx.x == 0) {
+        unsigned long long *r = g_trace + ((long)group * 4 + (j & 3)) * 4;
+        r[0] = trace_t0;
+        r[1] = __builtin_amdgcn_s_memrealtime();
+        r[2] = (unsigned long long)slow_steps;
+        r[3] = ((unsigned long long)blockIdx.x << 32) | __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    }
+#endif
     materialise_sk0(px, lazy);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -515,6 +553,50 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                     base + (long)(q * K + k) * n_pixels) = v;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launch order.  A wave that keeps leaving the fast step (its tile lies on a
+// moving object or on its edge) runs several times longer than the others;
+// there are only ~4 waves per slot in a launch, so where such waves start
+// decides when the launch ends.  Objects move little from one batch of frames
+// to the next: each launch records per block the largest number of slow
+// frames among its waves, and the next launch starts the blocks in 9 classes
+// of decreasing cost (the workgroup dispatcher hands blocks out in index
+// order).  Scheduling only: results do not depend on it.
+// One workgroup; reads cost[], writes order[], zeroes cost[].
+// ---------------------------------------------------------------------------
+constexpr int ORDER_CLASSES = 9;
+
+__global__ __launch_bounds__(1024) void mog_order_k(int *__restrict__ cost,
+                                                    int *__restrict__ order,
+                                                    int n_blocks,
+                                                    int frames_of_cost) {
+    __shared__ int count[ORDER_CLASSES], start[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) count[threadIdx.x] = 0;
+    __syncthreads();
+    auto cls = [&](int c) {
+        if (c <= 0) return ORDER_CLASSES - 1;
+        int q = (int)((long)c * (ORDER_CLASSES - 1) / (frames_of_cost + 1));
+        q = q < ORDER_CLASSES - 2 ? q : ORDER_CLASSES - 2;
+        return ORDER_CLASSES - 2 - q;           // 0 = slowest
+    };
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x)
+        atomicAdd(&count[cls(cost[b])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < ORDER_CLASSES; ++i) {
+            start[i] = acc;
+            acc += count[i];
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        const int pos = atomicAdd(&start[cls(cost[b])], 1);
+        order[pos] = b;
+        cost[b] = 0;
     }
 }
 
@@ -619,6 +701,10 @@ struct hk_mog {
     int nframes = 0;
     float *planes = nullptr;        // [NPLANES][n_pixels]
     float *alpha_table = nullptr;   // [HISTORY]
+    int *cost = nullptr;            // [n_groups] slow frames, last batch launch
+    int *order = nullptr;           // [n_groups] launch order, see mog_order_k
+    int n_groups = 0;
+    int frames_of_cost = 0;         // frames of the launch that wrote cost[]
     MogConst c;
 };
 
@@ -649,6 +735,13 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
     if (e == hipSuccess) e = hipMemset(m->planes, 0, bytes);
     if (e == hipSuccess)
         e = hipMalloc((void **)&m->alpha_table, sizeof(float) * HISTORY);
+    m->n_groups = (int)((m->n_pixels / 2 + 255) / 256);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&m->cost, sizeof(int) * 2 * m->n_groups);
+    if (e == hipSuccess) {
+        m->order = m->cost + m->n_groups;
+        e = hipMemset(m->cost, 0, sizeof(int) * 2 * m->n_groups);
+    }
     if (e == hipSuccess) {
         float tbl[HISTORY];
         for (int i = 0; i < HISTORY; ++i) tbl[i] = (float)(1. / (i + 1));
@@ -657,6 +750,7 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
     if (e != hipSuccess) {
         (void)hipFree(m->planes);
         (void)hipFree(m->alpha_table);
+        (void)hipFree(m->cost);
         delete m;
         return hk::fail(HK_ERR_ALLOC, "hk_mog_create: %s",
                         hipGetErrorString(e));
@@ -670,6 +764,7 @@ extern "C" int hk_mog_destroy(hk_mog *m) {
     hk::DeviceGuard guard(m->device);
     (void)hipFree(m->planes);
     (void)hipFree(m->alpha_table);
+    (void)hipFree(m->cost);
     delete m;
     return HK_OK;
 }
@@ -680,7 +775,10 @@ extern "C" int hk_mog_reset(hk_mog *m, void *stream) {
     HK_HIP(hipMemsetAsync(m->planes, 0,
                           sizeof(float) * NPLANES * (size_t)m->n_pixels,
                           (hipStream_t)stream));
+    HK_HIP(hipMemsetAsync(m->cost, 0, sizeof(int) * m->n_groups,
+                          (hipStream_t)stream));
     m->nframes = 0;
+    m->frames_of_cost = 0;
     return HK_OK;
 }
 
@@ -713,23 +811,37 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
         (nframes == 1 ||
          (bgr_frame_stride % 2 == 0 && mask_frame_stride % 2 == 0));
     if (fast) {
-        const long pairs = N / 2;
-        const unsigned blocks = (unsigned)((pairs + 255) / 256);
+        const unsigned blocks = (unsigned)((m->n_groups + 7) / 8) * 8 * 4;
         // short launches stream the model (HBM-bound), long ones are
         // bound by the latency of the frame loads and by arithmetic: see
         // mog_batch2_k
 #define HK_MOG_LAUNCH(W, D, TL)                                               \
-        hipLaunchKernelGGL((mog_batch2_k<W, D, TL>), dim3(blocks), dim3(256), \
+        hipLaunchKernelGGL((mog_batch2_k<W, D, TL>), dim3(blocks), dim3(64),  \
                            0, s, m->planes, N, m->width,                      \
                            (const uint8_t *)bgr_dev,                          \
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
                            mask_frame_stride, nframes, m->nframes,            \
-                           m->alpha_table, m->c)
+                           m->alpha_table, m->c, m->n_groups, order, cost)
         static const int variant = [] {
             const char *e = getenv("HK_MOG_VARIANT");
             return e ? atoi(e) : 0;
         }();
         const bool tileable = m->width % 32 == 0 && m->height % 4 == 0;
+        // batches are launched slowest blocks first (cost of the previous
+        // batch); single frames are not worth the bookkeeping
+        const int *order = nullptr;
+        int *cost = nullptr;
+        if (nframes > 4 && variant != 8) {
+            cost = m->cost;
+            if (m->frames_of_cost > 0) {
+                hipLaunchKernelGGL(mog_order_k, dim3(1), dim3(1024), 0, s,
+                                   m->cost, m->order, m->n_groups,
+                                   m->frames_of_cost);
+                HK_LAUNCH_CHECK("mog_order_k");
+                order = m->order;
+            }
+            m->frames_of_cost = nframes;
+        }
         if (nframes <= 4 && variant != 7) HK_MOG_LAUNCH(2, 1, false);
         else if (nframes <= 4) HK_MOG_LAUNCH(4, 1, false);
         else if (variant == 1) HK_MOG_LAUNCH(4, 2, false);
@@ -812,3 +924,10 @@ extern "C" int hk_mog_selfcheck_math(int device, long long *mismatches_out) {
     *mismatches_out = (long long)bad;
     return HK_OK;
 }
+
+#ifdef HK_MOG_TRACE
+extern "C" int hk_mog_trace_set(void *buf) {
+    unsigned long long *p = (unsigned long long *)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p));
+}
+#endif
