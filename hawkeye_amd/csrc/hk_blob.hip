@@ -16,7 +16,9 @@
 //                    foreground (possible raster-first pixel of a 4-connected
 //                    hole).  Wave-level ballot/prefix compaction, one atomic
 //                    per wave.
-//   K3 blob_trace_k  one lane per candidate follows the border exactly as
+//   K3 blob_trace_k  one workgroup per (frame, band of rows) copies the
+//                    band's 1-bit image (written by K2) into LDS; one lane per
+//                    candidate then follows its border exactly as
 //                    icvFetchContour does (same start direction, same sweep
 //                    order), accumulating the integer Green sums and
 //                    straight/diagonal step counts.  A candidate is the real
@@ -48,8 +50,10 @@
 namespace {
 
 constexpr int MAXPTS = 256;             // hard cap on a traced contour
-constexpr int CTR_NCAND = 0, CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
-constexpr unsigned FLAG_NONBINARY = 1u;
+constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
+constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
+constexpr unsigned BAND_CAP = 2048;     // candidates per (frame, band)
+constexpr int TRACE_LDS_BYTES = 128 * 1024;
 
 struct Cand {
     uint32_t pos;           // (y << 16) | x of the start (foreground) pixel
@@ -122,65 +126,59 @@ __device__ __forceinline__ unsigned row_bit(const uint8_t *row, int x, int W) {
 __global__ __launch_bounds__(256) void blob_scan_k(
     const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
     int H, int nframes, int segs, bool vec, Cand *__restrict__ cands,
-    unsigned *__restrict__ ctr, unsigned cap_cand) {
+    unsigned *__restrict__ ctr, int band_rows, int nbands,
+    unsigned short *__restrict__ bits, int words_per_row) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)nframes * H * segs;
-    unsigned outer = 0, hole = 0;
-    int f = 0, y = 0, x0 = 0;
+    if (tid >= total) return;
     bool nonbinary = false;
-    if (tid < total) {
-        const int seg = (int)(tid % segs);
-        const long rowid = tid / segs;
-        y = (int)(rowid % H);
-        f = (int)(rowid / H);
-        x0 = seg * 16;
-        const uint8_t *row = masks + (long)f * frame_stride + (long)y * pitch;
-        const uint8_t *prow = y > 0 ? row - pitch : nullptr;
-        // bit j of cur17 / up18 = pixel x0 - 1 + j
-        const unsigned cur17 = (row_bits16(row, x0, W, vec, nonbinary) << 1) |
-                               row_bit(row, x0 - 1, W);
-        bool dummy = false;
-        const unsigned up18 = (row_bits16(prow, x0, W, vec, dummy) << 1) |
-                              row_bit(prow, x0 - 1, W) |
-                              (row_bit(prow, x0 + 16, W) << 17);
-        const int nvalid = W - x0 < 16 ? W - x0 : 16;
-        const unsigned valid = (1u << nvalid) - 1u;
-        outer = (cur17 >> 1) & ~cur17 & ~up18 & ~(up18 >> 1) & ~(up18 >> 2) &
-                valid;
-        hole = ~(cur17 >> 1) & cur17 & (up18 >> 1) & valid;
-    }
+    const int seg = (int)(tid % segs);
+    const long rowid = tid / segs;
+    const int y = (int)(rowid % H);
+    const int f = (int)(rowid / H);
+    const int x0 = seg * 16;
+    const uint8_t *row = masks + (long)f * frame_stride + (long)y * pitch;
+    const uint8_t *prow = y > 0 ? row - pitch : nullptr;
+    // bit j of cur17 / up18 = pixel x0 - 1 + j
+    const unsigned cur17 = (row_bits16(row, x0, W, vec, nonbinary) << 1) |
+                           row_bit(row, x0 - 1, W);
+    bool dummy = false;
+    const unsigned up18 = (row_bits16(prow, x0, W, vec, dummy) << 1) |
+                          row_bit(prow, x0 - 1, W) |
+                          (row_bit(prow, x0 + 16, W) << 17);
+    const int nvalid = W - x0 < 16 ? W - x0 : 16;
+    const unsigned valid = (1u << nvalid) - 1u;
+    // the 1-bit image the border tracer reads: padded by one zero row
+    // above/below and one zero 32-bit word left/right (never written)
+    bits[((long)f * (H + 2) + y + 1) * words_per_row * 2 + 2 + seg] =
+        (unsigned short)((cur17 >> 1) & valid);
+    unsigned outer = (cur17 >> 1) & ~cur17 & ~up18 & ~(up18 >> 1) &
+                     ~(up18 >> 2) & valid;
+    unsigned hole = ~(cur17 >> 1) & cur17 & (up18 >> 1) & valid;
     if (nonbinary) atomicOr(&ctr[CTR_FLAGS], FLAG_NONBINARY);
 
+    // candidates go to the list of their (frame, band of rows); few 16-pixel
+    // segments hold any, so one atomic per such segment is cheap
     const unsigned c = __popc(outer) + __popc(hole);
-    if (__ballot(c != 0) == 0ull) return;       // wave-uniform
-
-    // inclusive prefix sum of c over the wave
-    const int lane = threadIdx.x & 63;
-    unsigned incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
-    }
-    const unsigned wave_total = __shfl(incl, 63, 64);
-    unsigned base = 0;
-    if (lane == 63) base = atomicAdd(&ctr[CTR_NCAND], wave_total);
-    base = __shfl(base, 63, 64);
-    unsigned at = base + incl - c;
+    if (c == 0) return;
+    const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
+    unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
+    if (at + c > BAND_CAP) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
+    Cand *list = cands + (size_t)bucket * BAND_CAP;
     while (outer) {
         const int i = __ffs(outer) - 1;
         outer &= outer - 1;
-        if (at < cap_cand)
-            cands[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i),
-                             (unsigned)f << 1};
+        if (at < BAND_CAP)
+            list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i),
+                            (unsigned)f << 1};
         ++at;
     }
     while (hole) {
         const int i = __ffs(hole) - 1;
         hole &= hole - 1;
-        if (at < cap_cand)      // origin = the foreground pixel left of it
-            cands[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
-                             ((unsigned)f << 1) | 1u};
+        if (at < BAND_CAP)      // origin = the foreground pixel left of it
+            list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
+                            ((unsigned)f << 1) | 1u};
         ++at;
     }
 }
@@ -188,21 +186,35 @@ __global__ __launch_bounds__(256) void blob_scan_k(
 // ---------------------------------------------------------------------------
 // K3
 // ---------------------------------------------------------------------------
-struct Img {
-    const uint8_t *p;
-    long pitch;
+// The same picture as 1 bit per pixel (written by blob_scan_k); `rows` is
+// the LDS copy of a band of it: all columns (one zero guard word on each
+// side), image rows row0 .. row0 + nrows - 1.  Every step of a border is a
+// dependent read of the 3x3 neighbourhood: from the byte image in HBM that is
+// 8 scattered loads and a memory round trip per step, here six LDS reads.
+struct BandImg {
+    const uint32_t *rows;   // LDS
+    int wpr, row0;
+    const uint32_t *frame;  // the padded frame in global memory (for fg())
     int W, H;
+
     __device__ __forceinline__ unsigned fg(int x, int y) const {
-        return (x >= 0 && x < W && y >= 0 && y < H)
-                   ? (unsigned)(p[(long)y * pitch + x] != 0)
-                   : 0u;
+        if (x < 0 || x >= W || y < 0 || y >= H) return 0u;
+        return (frame[(long)(y + 1) * wpr + 1 + (x >> 5)] >> (x & 31)) & 1u;
+    }
+    // bits x-1, x, x+1 of image row y
+    __device__ __forceinline__ unsigned three(int x, int y) const {
+        const uint32_t *q = rows + (y - row0) * wpr + 1 + ((x - 1) >> 5);
+        const unsigned long long v =
+            (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
+        return (unsigned)(v >> ((x - 1) & 31)) & 7u;
     }
     __device__ __forceinline__ unsigned ring(int x, int y) const {
-        unsigned m = 0;
-#pragma unroll
-        for (int d = 0; d < 8; ++d)
-            m |= fg(x + dir_dx(d), y + dir_dy(d)) << d;
-        return m;
+        const unsigned u = three(x, y - 1), m = three(x, y),
+                       d = three(x, y + 1);
+        // E NE N NW W SW S SE
+        return (m >> 2) | ((u >> 2) << 1) | (((u >> 1) & 1u) << 2) |
+               ((u & 1u) << 3) | ((m & 1u) << 4) | ((d & 1u) << 5) |
+               (((d >> 1) & 1u) << 6) | ((d >> 2) << 7);
     }
 };
 
@@ -216,12 +228,31 @@ __device__ __forceinline__ bool before(int x, int y, int rx, int ry) {
     return y < ry || (y == ry && x < rx);
 }
 
+// Bit d set iff the neighbour of (x, y) in direction d lies before (rx, ry)
+// in raster order (E NE N NW W SW S SE): before() for all 8 at once.
+__device__ __forceinline__ unsigned before_ring(int x, int y, int rx, int ry) {
+    const unsigned lm = x - 1 < rx, l0 = x < rx, lp = x + 1 < rx;
+    // pixels x+1, x, x-1 of a row, as direction bits of the row above
+    // (NE N NW = bits 1 2 3), the same row (E W = 0 4), the row below
+    // (SE S SW = 7 6 5)
+    const int dy = y - ry;
+    const unsigned up = dy <= 0 ? 0x0Eu
+                      : dy == 1 ? (lp << 1) | (l0 << 2) | (lm << 3) : 0u;
+    const unsigned mid = dy < 0 ? 0x11u : dy == 0 ? lp | (lm << 4) : 0u;
+    const unsigned dn = dy < -1 ? 0xE0u
+                      : dy == -1 ? (lp << 7) | (l0 << 6) | (lm << 5) : 0u;
+    return up | mid | dn;
+}
+
 // Border following from the foreground pixel (x0, y0), icvFetchContour order.
 // `hole` selects the start direction.  A trace is valid iff it closes within
 // max_pts points and (outer) visits no pixel before (x0, y0) in raster order
-// / (hole) examines no background pixel before (x0 + 1, y0).
-template <bool WRITE>
-__device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
+// / (hole) examines no background pixel before (x0 + 1, y0).  A border that
+// reaches a row more than max_pts / 2 below its start cannot close within
+// max_pts points (a step changes the row by at most one), so it is given up
+// there: no pixel below row y0 + max_pts / 2 + 1 is ever read.
+template <bool WRITE, class Image>
+__device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
                                int max_pts, ushort2 *__restrict__ pts) {
     Trace t{0, 0, 0, 0, 0, 0, false};
     const int rx = hole ? x0 + 1 : x0, ry = y0;
@@ -235,11 +266,15 @@ __device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
         return t;
     }
     // first neighbour clockwise from s0 (directions s0-1, s0-2, ...)
+    // (s0 = 0 for a hole: directions 7, 6, ... 1 are examined in turn)
     int s = s0;
     for (int j = 1; j < 8; ++j) {
         s = (s0 - j) & 7;
         if ((nb >> s) & 1u) break;
-        if (hole && before(x0 + dir_dx(s), y0 + dir_dy(s), rx, ry)) return t;
+    }
+    if (hole) {             // background pixels examined: directions s+1 .. 7
+        const unsigned seen = (0xFFu << (s + 1)) & 0xFFu;
+        if (before_ring(x0, y0, rx, ry) & seen) return t;
     }
     const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
 
@@ -249,11 +284,10 @@ __device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
         const int first = (s + 1) & 7;
         const unsigned rot = ((nb | (nb << 8)) >> first) & 0xFFu;
         const int skip = __ffs(rot) - 1;            // rot != 0 always
-        if (hole) {
-            for (int j = 0; j < skip; ++j) {
-                const int d = (first + j) & 7;
-                if (before(x3 + dir_dx(d), y3 + dir_dy(d), rx, ry)) return t;
-            }
+        if (hole) {         // background pixels examined: first .. first+skip-1
+            const unsigned run = (1u << skip) - 1u;
+            const unsigned seen = ((run << first) | (run << first >> 8)) & 0xFFu;
+            if (before_ring(x3, y3, rx, ry) & seen) return t;
         }
         s = (first + skip) & 7;
         const int x4 = x3 + dir_dx(s), y4 = y3 + dir_dy(s);
@@ -263,14 +297,16 @@ __device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
         if (WRITE) pts[t.npts] = make_ushort2((unsigned short)x3, (unsigned short)y3);
         ++t.npts;
         if (s & 1) ++t.nd; else ++t.ns;
-        const long long dxy = (long long)x3 * y4 - (long long)x4 * y3;
+        // x3*y4 - x4*y3 with (x4, y4) = (x3, y3) + step: small, 32-bit exact
+        const int dxy = x3 * dir_dy(s) - dir_dx(s) * y3;
         t.a00 += dxy;
-        t.a10 += dxy * (x3 + x4);
-        t.a01 += dxy * (y3 + y4);
+        t.a10 += (long long)dxy * (x3 + x4);
+        t.a01 += (long long)dxy * (y3 + y4);
 
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
         x3 = x4;
         y3 = y4;
+        if (y3 - y0 > max_pts / 2) return t;
         s = (s + 4) & 7;
         nb = img.ring(x3, y3);
     }
@@ -278,20 +314,46 @@ __device__ Trace follow_border(const Img img, int x0, int y0, bool hole,
     return t;
 }
 
-__global__ __launch_bounds__(64) void blob_trace_k(
-    const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
-    int H, const Cand *__restrict__ cands, unsigned *__restrict__ ctr,
-    unsigned cap_cand, BlobRec *__restrict__ recs, ushort2 *__restrict__ pts,
-    unsigned cap_blob, const DevParams prm) {
-    unsigned n = ctr[CTR_NCAND];
-    if (n > cap_cand) n = cap_cand;
-    for (unsigned i = blockIdx.x * 64u + threadIdx.x; i < n;
-         i += gridDim.x * 64u) {
-        const Cand c = cands[i];
+#ifdef HK_BLOB_TRACE
+__device__ unsigned long long *g_btrace = nullptr;      // scratch probe only
+#endif
+__global__ __launch_bounds__(256) void blob_trace_k(
+    const uint32_t *__restrict__ bits, int words_per_row, int W,
+    int H, int band_rows, int nbands, const Cand *__restrict__ cands,
+    unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
+    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm) {
+    extern __shared__ uint32_t band_lds[];
+    const unsigned bucket = blockIdx.x;
+    unsigned n = ctr[CTR_WORDS + bucket];
+#ifdef HK_BLOB_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr1 = tr0;
+    int tr_steps = 0;
+    if (g_btrace && threadIdx.x == 0) { g_btrace[bucket * 4] = tr0; g_btrace[bucket * 4 + 1] = tr0; g_btrace[bucket * 4 + 2] = tr0; g_btrace[bucket * 4 + 3] = n; }
+#endif
+    if (n == 0) return;                     // workgroup-uniform
+    if (n > BAND_CAP) n = BAND_CAP;
+    const int frame = (int)(bucket / (unsigned)nbands);
+    const int band = (int)(bucket % (unsigned)nbands);
+    // image rows band*band_rows - 1 .. + band_rows + max_pts/2 + 1
+    const int row0 = band * band_rows - 1;
+    int nrows = band_rows + prm.max_pts / 2 + 3;
+    if (row0 + nrows > H + 1) nrows = H + 1 - row0;
+    const uint32_t *fbits = bits + (long)frame * (H + 2) * words_per_row;
+    const uint32_t *src = fbits + (long)(row0 + 1) * words_per_row;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < nrows * words_per_row; i += 256)
+        band_lds[i] = src[i];
+    __syncthreads();
+#ifdef HK_BLOB_TRACE
+    tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const BandImg img{band_lds, words_per_row, row0, fbits, W, H};
+
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+        const Cand c = cands[(size_t)bucket * BAND_CAP + i];
         const int x0 = (int)(c.pos & 0xFFFFu), y0 = (int)(c.pos >> 16);
-        const int frame = (int)(c.fh >> 1);
         const bool hole = (c.fh & 1u) != 0u;
-        const Img img{masks + (long)frame * frame_stride, pitch, W, H};
 
         const Trace t = follow_border<false>(img, x0, y0, hole, prm.max_pts,
                                              nullptr);
@@ -342,6 +404,10 @@ __global__ __launch_bounds__(64) void blob_trace_k(
         (void)follow_border<true>(img, x0, y0, hole, prm.max_pts,
                                   pts + (size_t)slot * MAXPTS);
     }
+#ifdef HK_BLOB_TRACE
+    __syncthreads();
+    if (g_btrace && threadIdx.x == 0) { g_btrace[bucket * 4 + 1] = tr1; g_btrace[bucket * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -498,11 +564,15 @@ struct hk_blob {
     hk_blob_params params;
     DevParams dev;
     int n_thresholds = 0;
-    unsigned cap_cand = 0, cap_blob = 0, eager = 0;
+    unsigned cap_blob = 0, eager = 0;
+    int band_rows = 0, nbands = 0;      // K3 works on bands of rows
+    size_t trace_lds = 0;               // bytes of LDS a K3 workgroup needs
     Cand *cands = nullptr;
     unsigned *ctr = nullptr;
     BlobRec *recs = nullptr;
     ushort2 *pts = nullptr;
+    uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
+    int words_per_row = 0;              // (W + 31) / 32 + 2
     unsigned *h_ctr = nullptr;          // pinned
     BlobRec *h_recs = nullptr;          // pinned, cap_blob entries
     hipEvent_t done = nullptr;
@@ -537,6 +607,7 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->ctr);
     (void)hipFree(b->recs);
     (void)hipFree(b->pts);
+    (void)hipFree(b->bits);
     (void)hipHostFree(b->h_ctr);
     (void)hipHostFree(b->h_recs);
     if (b->done) (void)hipEventDestroy(b->done);
@@ -597,18 +668,45 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     for (double t = params->minThreshold; t < params->maxThreshold;
          t += params->thresholdStep)
         ++b->n_thresholds;
-    b->cap_cand = (unsigned)max_frames * 8192u;
+    // K3 holds band_rows + max_pts/2 + 3 rows of the 1-bit image in LDS
+    b->words_per_row = (width + 31) / 32 + 2;
+    {
+        const int row_bytes = 4 * b->words_per_row;
+        const int extra = max_pts / 2 + 3;
+        const int fit = TRACE_LDS_BYTES / row_bytes - extra;
+        if (fit < 8) {
+            delete b;
+            return hk::fail(HK_ERR_ARG,
+                            "hk_blob_create: frames wider than %d pixels are "
+                            "not supported",
+                            (TRACE_LDS_BYTES / (4 * (extra + 8)) - 2) * 32);
+        }
+        b->band_rows = std::min(std::min(fit, 64), height);
+        b->nbands = (height + b->band_rows - 1) / b->band_rows;
+        b->trace_lds = (size_t)row_bytes * (b->band_rows + extra);
+    }
+    const size_t nbuckets = (size_t)max_frames * b->nbands;
     b->cap_blob = (unsigned)max_frames * 128u;
     b->eager = std::min(b->cap_blob, (unsigned)max_frames * 48u);
 
-    hipError_t e = hipMalloc((void **)&b->cands, sizeof(Cand) * b->cap_cand);
+    hipError_t e = hipMalloc((void **)&b->cands,
+                             sizeof(Cand) * BAND_CAP * nbuckets);
+    if (e == hipSuccess)        // counters, then one candidate count per band
+        e = hipMalloc((void **)&b->ctr,
+                      sizeof(unsigned) * (CTR_WORDS + nbuckets));
     if (e == hipSuccess)
-        e = hipMalloc((void **)&b->ctr, sizeof(unsigned) * CTR_WORDS);
+        e = hipFuncSetAttribute((const void *)blob_trace_k,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TRACE_LDS_BYTES);
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->recs, sizeof(BlobRec) * b->cap_blob);
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->pts,
                       sizeof(ushort2) * MAXPTS * (size_t)b->cap_blob);
+    const size_t bit_bytes = sizeof(uint32_t) * (size_t)max_frames *
+                             (height + 2) * b->words_per_row;
+    if (e == hipSuccess) e = hipMalloc((void **)&b->bits, bit_bytes);
+    if (e == hipSuccess) e = hipMemset(b->bits, 0, bit_bytes);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&b->h_ctr, sizeof(unsigned) * CTR_WORDS);
     if (e == hipSuccess)
@@ -644,7 +742,9 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
     const hipStream_t s = (hipStream_t)stream;
     const uint8_t *masks = (const uint8_t *)mask_dev;
 
-    HK_HIP(hipMemsetAsync(b->ctr, 0, sizeof(unsigned) * CTR_WORDS, s));
+    const unsigned nbuckets = (unsigned)nframes * b->nbands;
+    HK_HIP(hipMemsetAsync(b->ctr, 0,
+                          sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
     const int segs = (b->width + 15) / 16;
     const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
                      (nframes == 1 || frame_stride % 16 == 0);
@@ -652,12 +752,13 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
     hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
                        dim3(256), 0, s, masks, frame_stride, pitch, b->width,
                        b->height, nframes, segs, vec, b->cands, b->ctr,
-                       b->cap_cand);
+                       b->band_rows, b->nbands, (unsigned short *)b->bits,
+                       b->words_per_row);
     HK_LAUNCH_CHECK("blob_scan_k");
-    hipLaunchKernelGGL(blob_trace_k, dim3(2048), dim3(64), 0, s, masks,
-                       frame_stride, pitch, b->width, b->height, b->cands,
-                       b->ctr, b->cap_cand, b->recs, b->pts, b->cap_blob,
-                       b->dev);
+    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(256), b->trace_lds,
+                       s, b->bits, b->words_per_row, b->width, b->height,
+                       b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
+                       b->pts, b->cap_blob, b->dev);
     HK_LAUNCH_CHECK("blob_trace_k");
     hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts);
@@ -682,14 +783,14 @@ static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
     const int nframes = b->pending_frames;
     b->pending_frames = 0;
     HK_HIP(hipEventSynchronize(b->done));
-    const unsigned ncand = b->h_ctr[CTR_NCAND], nblob = b->h_ctr[CTR_NBLOB];
+    const unsigned nblob = b->h_ctr[CTR_NBLOB];
     if (b->h_ctr[CTR_FLAGS] & FLAG_NONBINARY)
         return hk::fail(HK_ERR_ARG,
                         "hk_blob: mask holds values other than 0 and 255");
-    if (ncand > b->cap_cand)
+    if (b->h_ctr[CTR_FLAGS] & FLAG_BAND_FULL)
         return hk::fail(HK_ERR_CAPACITY,
-                        "hk_blob: %u border candidates exceed capacity %u",
-                        ncand, b->cap_cand);
+                        "hk_blob: more than %u border candidates in a band "
+                        "of %d rows", BAND_CAP, b->band_rows);
     if (nblob > b->cap_blob)
         return hk::fail(HK_ERR_CAPACITY,
                         "hk_blob: %u contours exceed capacity %u", nblob,
@@ -781,3 +882,10 @@ extern "C" int hk_blob_detect(hk_blob *b, const void *mask_dev,
     if (rc != HK_OK) return rc;
     return hk_blob_finish(b, counts_host, kp_host, cap, total);
 }
+
+#ifdef HK_BLOB_TRACE
+extern "C" int hk_blob_trace_set(void *buf) {
+    unsigned long long *p = (unsigned long long *)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_btrace), &p, sizeof(p));
+}
+#endif

@@ -2,6 +2,8 @@
 timings and event statistics (not part of the product)."""
 import sys, time
 import numpy as np
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hawkeye_amd import synth
 from hawkeye_amd.detect import BackgroundSubtractorMOG, SimpleBlobDetector

@@ -1,5 +1,7 @@
 """Scratch timing probe for the MOG kernels (not part of the product)."""
 import sys, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hawkeye_amd.detect import BackgroundSubtractorMOG
 
