@@ -21,6 +21,7 @@
 #include <thread>
 
 #include "hk_clip.h"
+#include "hk_seed.h"
 
 namespace hk {
 
@@ -215,6 +216,7 @@ public:
           nb_ptr_((size_t)c.n, nullptr), nb_len_((size_t)c.n, 0),
           nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           done_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
+          taken_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           done_at_((size_t)c.n, -1) {
         {   // top of the frame first; equal heights keep their tag order
             std::vector<std::pair<double, int>> keyed((size_t)c.n);
@@ -285,12 +287,17 @@ public:
         for (int i = 0; i < n_; ++i) {
             nb_state_[i].store(0, std::memory_order_relaxed);
             done_[i].store(0, std::memory_order_relaxed);
+            taken_[i].store(0, std::memory_order_relaxed);
         }
         for (int t = 0; t < nthreads_; ++t) scratch_[t].pool_reset();
 
+        const bool use_device = maxcount <= 0 && has_vmax_ && x_index_ok_ &&
+                                device_wanted();
         // the trial pass stops after a handful of arcs: keep its speculation
-        // shallow so that little work is thrown away
-        int per_thread = 256;
+        // shallow so that little work is thrown away.  With device results
+        // most seeds cost the workers nothing, so a short window keeps them
+        // busy and few results go stale before they are committed.
+        int per_thread = use_device ? 32 : 256;
         if (const char *e = getenv("HK_STEP3_WINDOW")) per_thread = atoi(e);
         size_t want = maxcount > 0 ? (size_t)nthreads_
                                    : (size_t)std::max(8, per_thread * nthreads_);
@@ -301,11 +308,31 @@ public:
         std::fill(done_at_.begin(), done_at_.end(), -1);
         n_accepted_ = 0;
         accepted_.store(0);
+        accepting_.store(0);
         next_.store(0);
         commit_pos_.store(0);
         stop_.store(false);
         stat_stale_ = stat_helped_ = 0;
         stat_stale_ms_ = 0;
+
+        // In the full pass the GPU evaluates windows of seeds ahead of the
+        // workers (hk_seed.hip); a worker that claims a seed whose device
+        // result is in takes that instead of running the seed.  The trial
+        // pass is short and stays on the host.
+        dev_ = nullptr;
+        dev_error_.store(HK_OK);
+        std::thread feeder;
+        if (use_device) {
+            const int rc = device_start();
+            if (rc != HK_OK) return rc;
+            if (dev_) feeder = std::thread([this] { feeder_loop(); });
+            // one window for the whole clip: nothing to do here before it
+            // is in (in a batch the other clips keep the cores busy)
+            if (dev_ && dev_window_ >= n_)
+                while (!dev_rounds_[0].ready.load(std::memory_order_acquire) &&
+                       dev_error_.load() == HK_OK)
+                    std::this_thread::yield();
+        }
 
         active_.store(nthreads_ - 1);
         generation_.fetch_add(1);               // release the workers
@@ -339,8 +366,10 @@ public:
                         std::chrono::steady_clock::now() - ts).count();
                 }
                 if (r.made) {
+                    accepting_.store(n_accepted_ + 1, std::memory_order_release);
                     for (int j : r.arc.tags) {
                         done_[j].store(1, std::memory_order_relaxed);
+                        taken_[j].store(1, std::memory_order_relaxed);
                         done_at_[(size_t)j] = (long)n_accepted_;
                     }
                     ++n_accepted_;
@@ -362,6 +391,14 @@ public:
         }
         stop_.store(true, std::memory_order_release);
         while (active_.load(std::memory_order_acquire) > 0) cpu_relax();
+        if (feeder.joinable()) feeder.join();
+        if (dev_) {
+            seed_close(dev_);
+            dev_ = nullptr;
+            if (rc == HK_OK && dev_error_.load() != HK_OK)
+                rc = fail(dev_error_.load(), "step 3 on the device: %s",
+                          dev_message_);
+        }
         stat_busy_ms_ = 0;
         for (int t = 0; t < nthreads_; ++t) {
             stat_busy_ms_ += scratch_[t].busy_ms;
@@ -369,6 +406,21 @@ public:
         }
         return rc;
     }
+
+    // Seeds on the GPU are opt-in (HK_STEP3_DEVICE=1; 2 = whatever the clip's
+    // size, for tests).  Measured on the 1080p60 benchmark clip (MI355X + 16
+    // host cores): the device results are exact and spare the host 41 % of
+    // its seed time, but one wave needs ~10 us per growth step against
+    // ~0.24 us on a host core, so a clip alone gets slower (the long seeds
+    // gate the launch: 11 ms) and a pipelined batch gains only ~8 %.
+    bool device_wanted() const {
+        const char *e = getenv("HK_STEP3_DEVICE");
+        if (!e) return false;
+        if (atoi(e) == 2) return true;
+        return atoi(e) == 1 && n_ >= 4096;
+    }
+
+    std::atomic<long> stat_dev_used_{0}, stat_dev_host_{0};
 
     long stat_stale_ = 0, stat_helped_ = 0;
     double stat_stale_ms_ = 0, stat_busy_ms_ = 0;
@@ -430,6 +482,151 @@ private:
         const int *begin() const { return p; }
         const int *end() const { return p + len; }
     };
+    struct DevRound {               // one window of seeds run on the device
+        std::atomic<int> ready{0};
+        size_t epoch = 0;           // arcs accepted when its flags were taken
+        SeedRound r;
+        std::vector<int> made_of;   // position in the window -> made_* index
+    };
+
+    static bool same_result(const SeedResult &a, const SeedResult &b) {
+        if (a.made != b.made) return false;
+        if (!a.made) return true;
+        const double pa[5] = {a.arc.a, a.arc.b, a.arc.c, a.arc.e, a.arc.f_peak};
+        const double pb[5] = {b.arc.a, b.arc.b, b.arc.c, b.arc.e, b.arc.f_peak};
+        return a.arc.tags == b.arc.tags &&
+               std::memcmp(pa, pb, sizeof(pa)) == 0;
+    }
+
+    int device_start() {
+        hk_clip &c = c_;
+        SeedParams prm;
+        prm.e0 = e0_;
+        prm.maxd = maxd_;
+        prm.rot_s = rot_.s;
+        prm.rot_c = rot_.c;
+        prm.v_max = v_max_;
+        prm.has_g = c.has_g ? 1 : 0;
+        prm.has_vmax = has_vmax_ ? 1 : 0;
+        prm.accel_lo = (1 - c.p.g_window) * c.g;
+        prm.accel_hi = (1 + c.p.g_window) * c.g;
+        {
+            const double max_cm_per_px = c.p.max_frame_height_cm / c.H;
+            prm.accel_floor = G_CM / (max_cm_per_px * (c.fps * c.fps));
+        }
+        prm.gap = c.p.max_frame_gap_in_arc;
+        prm.min_tags_to_curve_fit = c.p.min_tags_to_curve_fit;
+        prm.min_tags_per_arc = c.p.min_tags_per_arc;
+        // By default the whole clip is one window, run against the flags of
+        // the start, every seed to its end: most of the long-running seeds
+        // follow clutter tracks that no arc ever touches, so their results
+        // still hold when the committer gets to them.
+        prm.budget = 1 << 20;
+        if (const char *e = getenv("HK_STEP3_DEVICE_BUDGET"))
+            prm.budget = std::max(1, atoi(e));
+        dev_window_ = std::max(n_, 64);
+        if (const char *e = getenv("HK_STEP3_DEVICE_WINDOW"))
+            dev_window_ = std::max(64, atoi(e));
+        const int rc = seed_open(c, prm, queue_, qpos_, dev_window_, &dev_);
+        if (rc != HK_OK || !dev_) return rc;    // no device: host only
+        const int nw = seed_windows(dev_);
+        dev_rounds_.reset(new DevRound[(size_t)nw]);
+        stat_dev_used_.store(0);
+        stat_dev_host_.store(0);
+        return HK_OK;
+    }
+
+    // Launches window after window, each against the taken flags of the
+    // moment, never more than two windows ahead of the committer (a result
+    // computed long before its seed is committed is more likely stale) and
+    // never for seeds the workers have passed already.
+    void feeder_loop() {
+        const int nw = seed_windows(dev_);
+        std::vector<unsigned char> snap((size_t)n_);
+        for (int r = 0; r < nw; ++r) {
+            const size_t p0 = (size_t)r * (size_t)dev_window_;
+            int idle = 0;
+            while (!stop_.load(std::memory_order_acquire) &&
+                   p0 > commit_pos_.load(std::memory_order_acquire) +
+                            2 * (size_t)dev_window_) {
+                if (++idle > 200) {
+                    std::this_thread::yield();
+                    idle = 0;
+                } else {
+                    cpu_relax();
+                }
+            }
+            if (stop_.load(std::memory_order_acquire)) return;
+            if (p0 + (size_t)dev_window_ <=
+                next_.load(std::memory_order_relaxed))
+                continue;                       // the workers were faster
+            DevRound &d = dev_rounds_[(size_t)r];
+            // epoch first: a tag taken while the snapshot is copied may or
+            // may not be in it, and then counts as taken after the epoch
+            d.epoch = accepted_.load(std::memory_order_acquire);
+            for (int i = 0; i < n_; ++i)
+                snap[(size_t)i] = done_[i].load(std::memory_order_relaxed);
+            const int rc = seed_round(dev_, r, snap.data(), d.r);
+            if (rc != HK_OK) {
+                snprintf(dev_message_, sizeof(dev_message_), "%s",
+                         error_buffer());
+                dev_error_.store(rc);
+                return;
+            }
+            d.made_of.assign((size_t)d.r.count, -1);
+            for (int m = 0; m < d.r.made_count; ++m)
+                d.made_of[(size_t)d.r.made_seed[m]] = m;
+            d.ready.store(1, std::memory_order_release);
+        }
+    }
+
+    // The device's result for queue position p, if there is one that counts.
+    bool take_device_result(size_t p, Slot &slot) {
+        DevRound &d = dev_rounds_[p / (size_t)dev_window_];
+        if (!d.ready.load(std::memory_order_acquire)) return false;
+        const int k = (int)(p - (size_t)d.r.p0);
+        const int st = d.r.status[k];
+        if (st != S3_NONE && st != S3_MADE) {
+            stat_dev_host_.fetch_add(1, std::memory_order_relaxed);
+            return false;
+        }
+        // The device saw the flags of an earlier moment.  Its result holds
+        // now if none of the tags it looked at has been taken since (then it
+        // is the result a run started now would give); later acceptances are
+        // the committer's staleness test, from this epoch on.
+        SeedResult &res = slot.res;
+        const int *cons = d.r.cons + (size_t)k * S3_CONSULTED;
+        const size_t epoch = accepted_.load(std::memory_order_acquire);
+        for (int q = 0; q < d.r.n_cons[k]; ++q)
+            if (done_at_now(cons[q])) {
+                stat_dev_host_.fetch_add(1, std::memory_order_relaxed);
+                return false;
+            }
+        res.consulted.assign(cons, cons + d.r.n_cons[k]);
+        res.made = st == S3_MADE;
+        if (res.made) {
+            const int m = d.made_of[(size_t)k];
+            const double *pp = d.r.made_params + 5 * (size_t)m;
+            res.arc = Arc();
+            res.arc.a = pp[0];
+            res.arc.b = pp[1];
+            res.arc.c = pp[2];
+            res.arc.e = pp[3];
+            res.arc.f_peak = pp[4];
+            const int *mem = d.r.made_members + (size_t)m * S3_MEMBERS;
+            res.arc.tags.assign(mem, mem + d.r.made_n[m]);
+        }
+        slot.epoch = epoch;
+        stat_dev_used_.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+
+
+    // tag j belongs to an accepted arc (committed seeds that made no arc are
+    // "done" only in the sense that they come earlier in the queue)
+    bool done_at_now(int j) const {
+        return taken_[j].load(std::memory_order_acquire) != 0;
+    }
 
     bool is_done(int j, int pos) const {
         return qpos_[(size_t)j] < pos ||
@@ -452,6 +649,25 @@ private:
         const int t1 = queue_[p];
         if (done_[t1].load(std::memory_order_relaxed)) {
             slot.skipped = true;
+        } else if (dev_ && take_device_result(p, slot)) {
+            slot.skipped = false;
+            if (g_self_check.load(std::memory_order_relaxed)) {
+                // the host's own result against the same flags: what the
+                // device saw as taken is a subset of what is taken now, so
+                // only compare when nothing was accepted since
+                SeedResult mine;
+                const size_t before = slot.epoch;
+                run_seed(t1, (int)p, s, mine);
+                if (accepting_.load(std::memory_order_acquire) == before &&
+                    !same_result(mine, slot.res)) {
+                    snprintf(dev_message_, sizeof(dev_message_),
+                             "self check: device and host disagree on seed "
+                             "%zu (tag %d): host %s, device %s", p, t1,
+                             mine.made ? "arc" : "no arc",
+                             slot.res.made ? "arc" : "no arc");
+                    dev_error_.store(HK_ERR_INTERNAL);
+                }
+            }
         } else {
             slot.skipped = false;
             slot.epoch = accepted_.load(std::memory_order_acquire);
@@ -795,6 +1011,11 @@ private:
 
     hk_clip &c_;
     const int n_;
+    SeedDevice *dev_ = nullptr;         // full pass only
+    int dev_window_ = 0;
+    std::unique_ptr<DevRound[]> dev_rounds_;
+    std::atomic<int> dev_error_{0};
+    char dev_message_[256] = {0};
     std::vector<int> queue_, qpos_;     // seeds top of the frame first
     std::vector<int> xs_idx_;           // tags by (frame, x)
     std::vector<double> xs_val_;        // their x
@@ -803,6 +1024,7 @@ private:
     std::vector<int> nb_len_;
     std::unique_ptr<std::atomic<uint8_t>[]> nb_state_;
     std::unique_ptr<std::atomic<uint8_t>[]> done_;
+    std::unique_ptr<std::atomic<uint8_t>[]> taken_;  // member of an accepted arc
     std::unique_ptr<Scratch[]> scratch_;
     std::unique_ptr<Slot[]> slots_;
     size_t window_ = 1;
@@ -812,6 +1034,7 @@ private:
     alignas(128) std::atomic<size_t> next_{0};
     alignas(128) std::atomic<size_t> commit_pos_{0};
     alignas(128) std::atomic<size_t> accepted_{0};
+    std::atomic<size_t> accepting_{0};  // accepted_, raised before the flags
     alignas(128) std::atomic<int> active_{0};
     std::atomic<unsigned> generation_{0};
     std::atomic<bool> quit_{false}, stop_{false};
@@ -1378,9 +1601,11 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
             fprintf(stderr,
                     "step3: trial pass %.1f ms, full pass %.1f ms (%ld stale "
                     "results recomputed in %.1f ms, committer ran %ld seeds, "
-                    "seed time summed over threads %.1f ms)\n",
+                    "seed time summed over threads %.1f ms; device results "
+                    "used %ld, handed back %ld)\n",
                     ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_stale_ms_,
-                    b.stat_helped_, b.stat_busy_ms_);
+                    b.stat_helped_, b.stat_busy_ms_, b.stat_dev_used_.load(),
+                    b.stat_dev_host_.load());
     }
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;
@@ -1478,6 +1703,7 @@ extern "C" int hk_clip_member_distances(hk_clip *c, double *dist,
 }
 
 extern "C" int hk_release_cached_memory(void) {
+    hk::seed_release_cached();
     hk::em_release_cached();
     return HK_OK;
 }

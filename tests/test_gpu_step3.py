@@ -1,0 +1,84 @@
+"""
+GPU: step 3 with its seeds evaluated on the device (hk_seed.hip, through the
+C ABI) against the host code path, bit for bit: same arcs, same members, same
+parameters; with the library's self check on, every single seed's device
+result is compared with the host's.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def tags_with_distractors(width, height, fps, balls, frames, seed, clutter,
+                          walkers):
+    from hawkeye_amd import synth
+    scene = synth.JugglingScene(width, height, fps, balls, frames, seed)
+    meas = synth.make_tags(scene, seed + 1, clutter_per_frame=clutter)
+    rng = np.random.RandomState(seed + 2)
+    for d in range(walkers):                # random-walk distractors
+        px, py = rng.uniform(0.1, 0.9) * width, rng.uniform(0.1, 0.9) * height
+        for f in range(frames):
+            px += rng.normal(0, 1.2)
+            py += rng.normal(0, 1.2)
+            meas.setdefault(f, []).append((px, py, 14.0 + d))
+    return synth.tags_to_soa(meas, frames)
+
+
+def build(monkeypatch, geometry, soa, device, window=None, self_check=False):
+    from hawkeye_amd import _native as nat
+    from hawkeye_amd.arcs import Clip
+    width, height, fps, frames = geometry
+    frame, x, y, r, tw, start = soa
+    monkeypatch.setenv('HK_STEP3_DEVICE', '2' if device else '0')
+    if window:
+        monkeypatch.setenv('HK_STEP3_DEVICE_WINDOW', str(window))
+    else:
+        monkeypatch.delenv('HK_STEP3_DEVICE_WINDOW', raising=False)
+    nat.check(nat.lib.hk_set_self_check(1 if self_check else 0))
+    try:
+        clip = Clip(width, height, fps, frames, frame, x, y, r, tw, stream=0)
+        clip.build_initial_arcs()
+        params, ids, tags = clip.arcs()
+        g = clip.state()['g_px_per_frame_sq']
+        clip.close()
+    finally:
+        nat.check(nat.lib.hk_set_self_check(0))
+    return (params.tobytes(), ids.tobytes(), tuple(t.tobytes() for t in tags),
+            g)
+
+
+@pytest.mark.parametrize('geometry,balls,clutter,walkers,seed', [
+    ((1280, 720, 60.0, 400), 7, 15.0, 6, 901),
+    ((1920, 1080, 60.0, 600), 9, 6.0, 20, 17),
+    ((960, 540, 30.0, 300), 3, 2.0, 0, 5),
+])
+def test_device_seeds_equal_host_seeds(monkeypatch, geometry, balls, clutter,
+                                       walkers, seed):
+    soa = tags_with_distractors(geometry[0], geometry[1], geometry[2], balls,
+                                geometry[3], seed, clutter, walkers)
+    want = build(monkeypatch, geometry, soa, device=False)
+    assert len(want[2]) > 10
+    # every seed cross-checked inside the library, several window sizes (the
+    # smaller the window, the fewer results go stale)
+    assert build(monkeypatch, geometry, soa, True, self_check=True) == want
+    for window in (64, 1000, 100000):
+        assert build(monkeypatch, geometry, soa, True, window=window) == want
+
+
+def test_device_path_on_golden_run(monkeypatch, golden_dir):
+    """The 1080p60 golden run of the reference through the device path."""
+    import json
+    import os
+    from hawkeye_amd import synth
+    with open(os.path.join(golden_dir, 'run_noisy_1080p60_9ball.json')) as fh:
+        run = json.load(fh)
+    meas = {int(f): [tuple(t) for t in lst] for f, lst in run['meas'].items()}
+    soa = synth.tags_to_soa(meas, run['frames'])
+    geometry = (run['width'], run['height'], run['fps'], run['frames'])
+    host = build(monkeypatch, geometry, soa, device=False)
+    dev = build(monkeypatch, geometry, soa, device=True, self_check=True)
+    assert dev == host
+    assert len(dev[2]) == len(run['step3']['arcs'])

@@ -1,4 +1,6 @@
 import sys, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from hawkeye_amd.arcs import Clip
 d = np.load(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/events_C_1080p60_9ball_noisy.npz')
