@@ -255,10 +255,12 @@ def main():
         'algorithmic_bytes_per_launch': int(ALGO_BYTES_PER_PIXEL_FRAME * px *
                                             launch_frames),
         'kernel_fps': round(launch_frames / (launch_ms * 1e-3), 1),
-        'note': 'model stays in registers across the frames of a launch, so '
-                'physical traffic is ~9 B/px/frame (see traffic), not the '
-                'algorithmic 324: frac > 1 is real, the kernel is bound by '
-                'VALU issue, not HBM (DESIGN.md section 4)',
+        'note': 'the model stays on chip (registers + LDS) across the frames '
+                'of a launch and planes of components never created are not '
+                'touched, so physical traffic is ~6.6 B/px/frame (see '
+                'traffic), not the algorithmic 324: frac > 1 is real; the '
+                'kernel is bound by VALU issue plus the divergence of waves '
+                'that hold moving-object pixels (DESIGN.md section 4)',
     }
     if traffic is not None:
         roofline['traffic_source'] = traffic.get('source')

@@ -314,9 +314,6 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
     return t;
 }
 
-#ifdef HK_BLOB_TRACE
-__device__ unsigned long long *g_btrace = nullptr;      // scratch probe only
-#endif
 __global__ __launch_bounds__(256) void blob_trace_k(
     const uint32_t *__restrict__ bits, int words_per_row, int W,
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
@@ -325,12 +322,6 @@ __global__ __launch_bounds__(256) void blob_trace_k(
     extern __shared__ uint32_t band_lds[];
     const unsigned bucket = blockIdx.x;
     unsigned n = ctr[CTR_WORDS + bucket];
-#ifdef HK_BLOB_TRACE
-    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tr1 = tr0;
-    int tr_steps = 0;
-    if (g_btrace && threadIdx.x == 0) { g_btrace[bucket * 4] = tr0; g_btrace[bucket * 4 + 1] = tr0; g_btrace[bucket * 4 + 2] = tr0; g_btrace[bucket * 4 + 3] = n; }
-#endif
     if (n == 0) return;                     // workgroup-uniform
     if (n > BAND_CAP) n = BAND_CAP;
     const int frame = (int)(bucket / (unsigned)nbands);
@@ -345,9 +336,6 @@ __global__ __launch_bounds__(256) void blob_trace_k(
     for (int i = threadIdx.x; i < nrows * words_per_row; i += 256)
         band_lds[i] = src[i];
     __syncthreads();
-#ifdef HK_BLOB_TRACE
-    tr1 = __builtin_amdgcn_s_memrealtime();
-#endif
     const BandImg img{band_lds, words_per_row, row0, fbits, W, H};
 
     for (unsigned i = threadIdx.x; i < n; i += 256) {
@@ -404,10 +392,6 @@ __global__ __launch_bounds__(256) void blob_trace_k(
         (void)follow_border<true>(img, x0, y0, hole, prm.max_pts,
                                   pts + (size_t)slot * MAXPTS);
     }
-#ifdef HK_BLOB_TRACE
-    __syncthreads();
-    if (g_btrace && threadIdx.x == 0) { g_btrace[bucket * 4 + 1] = tr1; g_btrace[bucket * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -883,9 +867,3 @@ extern "C" int hk_blob_detect(hk_blob *b, const void *mask_dev,
     return hk_blob_finish(b, counts_host, kp_host, cap, total);
 }
 
-#ifdef HK_BLOB_TRACE
-extern "C" int hk_blob_trace_set(void *buf) {
-    unsigned long long *p = (unsigned long long *)buf;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_btrace), &p, sizeof(p));
-}
-#endif

@@ -9,10 +9,12 @@
 // wave's 64 lanes touch 64 consecutive floats (or float4s) of one plane.
 // Plane p = field*5 + k, fields in the order of enum Field.
 //
-// The recursion is independent per pixel, so one launch can advance a pixel
-// through many frames with its whole mixture held in registers: per frame
-// only the 3 input bytes are read and the mask byte written.  hk_mog_apply is
-// the same kernel with one frame.
+// The recursion is independent per pixel, so one launch advances a pixel
+// through many frames with its mixture held on chip: per frame only the 3
+// input bytes are read and the mask byte written.  hk_mog_apply is the same
+// kernel with one frame.  Pixels are handled in pairs: the common case (both
+// match their first component, the background mode) runs in packed fp32
+// (v_pk_*), anything else through the general per-pixel step.
 //
 // Arithmetic is bit-identical to the oracle: same fp32 operation order, no
 // FMA contraction (-ffp-contract=off), IEEE divide and sqrt
@@ -20,7 +22,6 @@
 
 #include <cfloat>
 #include <cstdint>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -359,22 +360,22 @@ __device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
 }
 
 // ---------------------------------------------------------------------------
-// Fast path: contiguous frames, N % 2 == 0.  Each lane owns 2 consecutive
-// pixels: three 2-byte loads and one 2-byte store per frame, float2 plane
-// accesses once per launch.
+// Fast path: contiguous frames, N % 2 == 0.  Each lane owns 2 neighbouring
+// pixels (a 6-byte load and a 2-byte store per frame), the model is read once
+// and written once per launch.
 //
-// The kernel is bound by VALU issue, not by HBM (the model never leaves the
-// registers during a launch), so what matters is waves per SIMD: with several
-// waves resident, one wave's scalar/branch instructions and divide/sqrt
-// latencies hide behind another's arithmetic.  WAVES = 4 caps the kernel at
-// 128 VGPRs (a few rarely-live values spill to scratch): best for long
-// batches.  WAVES = 2 (no spills) is best when a launch is a single frame and
-// the 320 B/pixel of model traffic dominate.
+// What bounds it (MI355X, 1080p, 128 frames per launch, rocprofv3 counters):
+// on a static scene the four SIMDs of every CU issue vector instructions
+// back to back (~90 per wave and frame at 4 cycles each; 0.39 ms per launch,
+// 2.4 TB/s of HBM traffic) -- VALU issue.  A scene with moving objects adds
+// the general step for the waves that contain a pixel off its background
+// mode (~8 % of wave-frames with 128-pixel runs per wave, ~3 % with 32 x 4
+// tiles) and a tail: such waves run several times longer than the others and
+// there are only four waves per slot in a launch.  Hence the tiles, one wave
+// per workgroup, and the launch order (mog_order_k).  4 waves per SIMD need
+// 128 VGPRs: the rarely used half of the model sits in LDS, DEPTH frames of
+// input are requested ahead (every frame's bytes are an HBM miss).
 // ---------------------------------------------------------------------------
-#ifdef HK_MOG_TRACE
-__device__ unsigned long long *g_trace = nullptr;   // scratch probe only
-#endif
-
 template <int WAVES, int DEPTH, bool TILED>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
@@ -449,9 +450,6 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     LazySK lazy;
     lazy.w = lazy.s = lazy.scale = f2{0.f, 0.f};
     int slow_steps = 0;     // frames in which this wave left the fast step
-#ifdef HK_MOG_TRACE
-    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // The 6 input bytes of a frame are far from those of the next frame, so
     // every load is an HBM miss (~2 us under load): the frames of the next
@@ -522,15 +520,6 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 
     if (cost && threadIdx.x == 0 && slow_steps)
         atomicMax(&cost[group], slow_steps);
-#ifdef HK_MOG_TRACE
-    if (g_trace && threadIdx.x == 0) {
-        unsigned long long *r = g_trace + ((long)group * 4 + (j & 3)) * 4;
-        r[0] = trace_t0;
-        r[1] = __builtin_amdgcn_s_memrealtime();
-        r[2] = (unsigned long long)slow_steps;
-        r[3] = ((unsigned long long)blockIdx.x << 32) | __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-    }
-#endif
     materialise_sk0(px, lazy);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -822,16 +811,12 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
                            mask_frame_stride, nframes, m->nframes,            \
                            m->alpha_table, m->c, m->n_groups, order, cost)
-        static const int variant = [] {
-            const char *e = getenv("HK_MOG_VARIANT");
-            return e ? atoi(e) : 0;
-        }();
         const bool tileable = m->width % 32 == 0 && m->height % 4 == 0;
-        // batches are launched slowest blocks first (cost of the previous
+        // batches are launched slowest groups first (cost of the previous
         // batch); single frames are not worth the bookkeeping
         const int *order = nullptr;
         int *cost = nullptr;
-        if (nframes > 4 && variant != 8) {
+        if (nframes > 4) {
             cost = m->cost;
             if (m->frames_of_cost > 0) {
                 hipLaunchKernelGGL(mog_order_k, dim3(1), dim3(1024), 0, s,
@@ -842,14 +827,13 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
             }
             m->frames_of_cost = nframes;
         }
-        if (nframes <= 4 && variant != 7) HK_MOG_LAUNCH(2, 1, false);
-        else if (nframes <= 4) HK_MOG_LAUNCH(4, 1, false);
-        else if (variant == 1) HK_MOG_LAUNCH(4, 2, false);
-        else if (variant == 2 || !tileable) HK_MOG_LAUNCH(4, 4, false);
-        else if (variant == 3) HK_MOG_LAUNCH(4, 2, true);
-        else if (variant == 5) HK_MOG_LAUNCH(4, 8, true);
-        else if (variant == 6) HK_MOG_LAUNCH(4, 1, false);
-        else HK_MOG_LAUNCH(4, 4, true);
+        if (nframes <= 4) {
+            if (tileable) HK_MOG_LAUNCH(4, 1, true);
+            else HK_MOG_LAUNCH(4, 1, false);
+        } else {
+            if (tileable) HK_MOG_LAUNCH(4, 4, true);
+            else HK_MOG_LAUNCH(4, 4, false);
+        }
 #undef HK_MOG_LAUNCH
         HK_LAUNCH_CHECK("mog_batch2_k");
     } else {
@@ -925,9 +909,3 @@ extern "C" int hk_mog_selfcheck_math(int device, long long *mismatches_out) {
     return HK_OK;
 }
 
-#ifdef HK_MOG_TRACE
-extern "C" int hk_mog_trace_set(void *buf) {
-    unsigned long long *p = (unsigned long long *)buf;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p));
-}
-#endif
