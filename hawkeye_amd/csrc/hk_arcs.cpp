@@ -22,6 +22,7 @@
 
 #include "hk_clip.h"
 #include "hk_seed.h"
+#include "hk_simd.h"
 
 namespace hk {
 
@@ -237,6 +238,10 @@ public:
                 queue_[(size_t)k] = keyed[(size_t)k].second;
         }
         for (int k = 0; k < n_; ++k) qpos_[(size_t)queue_[(size_t)k]] = k;
+        tag_.resize((size_t)c.n);
+        for (int i = 0; i < c.n; ++i)
+            tag_[(size_t)i] = TagRec{c.x[i], c.y[i], c.frame[i],
+                                     qpos_[(size_t)i]};
         // per frame, the tags ordered by x (for the neighbour search)
         xs_idx_.resize((size_t)c.n);
         xs_val_.resize((size_t)c.n);
@@ -429,17 +434,22 @@ public:
 private:
     // neighbour lists live in per-thread chunked pools (no malloc per tag)
     struct alignas(128) Scratch {   // own cache lines: no false sharing
-        std::vector<int> in_frontier, taken, members, frontier, cand, order;
-        std::vector<double> vel, mf, mx, my, fq;
-        std::vector<int> seen;          // per run: tag already in `consulted`
+        // per tag: run stamp of `consulted`, trial stamp of the frontier
+        struct Marks {
+            int seen, in_frontier;
+        };
+        std::vector<Marks> marks;
+        std::vector<int> taken, members, frontier, cand, order;
+        // the frontier tags' frame, x, y travel with them (no gathers in
+        // the distance loop)
+        std::vector<double> vel, mf, mx, my, fq, ff, fx, fy;
         int stamp = 0, run_stamp = 0;
         double busy_ms = 0;
         std::vector<std::unique_ptr<int[]>> chunks;
         size_t chunk_used = 0, chunk_index = 0;
         static constexpr size_t CHUNK = 1 << 16;
         void init(int n, int F) {
-            in_frontier.assign((size_t)n, 0);
-            seen.assign((size_t)n, 0);
+            marks.assign((size_t)n, Marks{0, 0});
             taken.assign((size_t)(F > 0 ? F : 1), 0);
         }
         void pool_reset() {
@@ -808,20 +818,58 @@ private:
     }
 
     static void consult(int j, Scratch &s, SeedResult &res) {
-        if (s.seen[j] != s.run_stamp) {
-            s.seen[j] = s.run_stamp;
+        if (s.marks[(size_t)j].seen != s.run_stamp) {
+            s.marks[(size_t)j].seen = s.run_stamp;
             res.consulted.push_back(j);
         }
     }
 
+    // The frontier additions a member i brings: its neighbours.  Neither the
+    // frontier nor the consulted set depends on the order they are visited
+    // in, so without a speed cap (trial pass: every tag of the frames around
+    // i qualifies) the two index ranges are walked directly -- no list, no
+    // distances, no sort; the ordered list is only built for seeds.
+    void add_neighbors_to_frontier(int i, int pos, Scratch &s,
+                                   SeedResult &res) {
+        if (has_vmax_) {
+            add_to_frontier(neighbors(i, s), pos, s, res);
+            return;
+        }
+        const hk_clip &c = c_;
+        const int f = c.frame[i];
+        const int gap = c.p.max_frame_gap_in_arc;
+        const int lo = std::max(0, f - gap - 1);
+        const int hi = std::min(c.F, f + gap + 2);
+        add_range_to_frontier(c.start[lo], c.start[f], pos, s, res);
+        add_range_to_frontier(c.start[f + 1], c.start[hi], pos, s, res);
+    }
+
+    void add_range_to_frontier(int j0, int j1, int pos, Scratch &s,
+                               SeedResult &res) {
+        for (int j = j0; j < j1; ++j) add_one_to_frontier(j, pos, s, res);
+    }
+
     void add_to_frontier(Span src, int pos, Scratch &s, SeedResult &res) {
-        for (int j : src) {
-            if (is_done(j, pos)) continue;
-            consult(j, s, res);
-            if (s.taken[c_.frame[j]] == s.stamp || s.in_frontier[j] == s.stamp)
-                continue;
-            s.in_frontier[j] = s.stamp;
+        for (int j : src) add_one_to_frontier(j, pos, s, res);
+    }
+
+    void add_one_to_frontier(int j, int pos, Scratch &s, SeedResult &res) {
+        {
+            const TagRec &t = tag_[(size_t)j];
+            if (t.qpos < pos || done_[j].load(std::memory_order_relaxed))
+                return;
+            Scratch::Marks &m = s.marks[(size_t)j];
+            if (m.seen != s.run_stamp) {
+                m.seen = s.run_stamp;
+                res.consulted.push_back(j);
+            }
+            if (s.taken[t.frame] == s.stamp || m.in_frontier == s.stamp)
+                return;
+            m.in_frontier = s.stamp;
             s.frontier.push_back(j);
+            s.ff.push_back((double)t.frame);
+            s.fx.push_back(t.x);
+            s.fy.push_back(t.y);
         }
     }
 
@@ -854,6 +902,15 @@ private:
         if (n < 3) return;
         Moments m;
         const double fp = arc.f_peak;
+        if (simd_) {
+            double v[11];
+            simd_moments(s.mf.data(), s.mx.data(), s.my.data(), n, fp, v);
+            m.T0 = v[0]; m.T1 = v[1]; m.T2 = v[2]; m.T3 = v[3]; m.T4 = v[4];
+            m.X1 = v[5]; m.TX = v[6]; m.T2X = v[7];
+            m.Y1 = v[8]; m.TY = v[9]; m.T2Y = v[10];
+            solve_fit(arc, m, rot_);
+            return;
+        }
         for (size_t i = 0; i < n; ++i) {
             const double t = s.mf[i] - fp;
             const double x = s.mx[i], y = s.my[i];
@@ -902,8 +959,11 @@ private:
             s.taken[f1] = s.stamp;
             s.taken[f2] = s.stamp;
             s.frontier.clear();
+            s.ff.clear();
+            s.fx.clear();
+            s.fy.clear();
             add_to_frontier(nb1, pos, s, res);
-            add_to_frontier(neighbors(t2, s), pos, s, res);
+            add_neighbors_to_frontier(t2, pos, s, res);
 
             arc.e = e0_;
             arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
@@ -924,12 +984,20 @@ private:
                 const size_t nf = s.frontier.size();
                 s.fq.resize(nf);
                 double q_min = 0;
-                for (size_t i = 0; i < nf; ++i) {
-                    const int j = s.frontier[i];
-                    const double q =
-                        dist_sq(arc, (double)c.frame[j], c.x[j], c.y[j]);
-                    s.fq[i] = q;
-                    if (i == 0 || q < q_min) q_min = q;
+                if (simd_) {
+                    const double p5[5] = {arc.a, arc.b, arc.c, arc.e,
+                                          arc.f_peak};
+                    simd_dist_sq(p5, rot_.s, rot_.c, s.ff.data(), s.fx.data(),
+                                 s.fy.data(), nf, s.fq.data());
+                    for (size_t i = 0; i < nf; ++i)
+                        if (i == 0 || s.fq[i] < q_min) q_min = s.fq[i];
+                } else {
+                    for (size_t i = 0; i < nf; ++i) {
+                        const double q =
+                            dist_sq(arc, s.ff[i], s.fx[i], s.fy[i]);
+                        s.fq[i] = q;
+                        if (i == 0 || q < q_min) q_min = q;
+                    }
                 }
                 int best = -1;
                 double best_d = 0;
@@ -961,18 +1029,33 @@ private:
                 const size_t at = (size_t)(
                     std::upper_bound(members.begin(), members.end(), best) -
                     members.begin());
+                const TagRec &tb = tag_[(size_t)best];
                 members.insert(members.begin() + (long)at, best);
-                s.mf.insert(s.mf.begin() + (long)at, (double)c.frame[best]);
-                s.mx.insert(s.mx.begin() + (long)at, c.x[best]);
-                s.my.insert(s.my.begin() + (long)at, c.y[best]);
-                s.taken[c.frame[best]] = s.stamp;
-                add_to_frontier(neighbors(best, s), pos, s, res);
-                s.frontier.erase(
-                    std::remove_if(s.frontier.begin(), s.frontier.end(),
-                                   [&](int j) {
-                                       return s.taken[c.frame[j]] == s.stamp;
-                                   }),
-                    s.frontier.end());
+                s.mf.insert(s.mf.begin() + (long)at, (double)tb.frame);
+                s.mx.insert(s.mx.begin() + (long)at, tb.x);
+                s.my.insert(s.my.begin() + (long)at, tb.y);
+                s.taken[tb.frame] = s.stamp;
+                add_neighbors_to_frontier(best, pos, s, res);
+                {   // drop the frontier tags of the frame just taken (the
+                    // only frame that became taken; order is kept)
+                    const double fb = (double)tb.frame;
+                    const size_t nfr = s.frontier.size();
+                    size_t k = 0;
+                    for (size_t i = 0; i < nfr; ++i) {
+                        if (s.ff[i] == fb) continue;
+                        if (k != i) {
+                            s.frontier[k] = s.frontier[i];
+                            s.ff[k] = s.ff[i];
+                            s.fx[k] = s.fx[i];
+                            s.fy[k] = s.fy[i];
+                        }
+                        ++k;
+                    }
+                    s.frontier.resize(k);
+                    s.ff.resize(k);
+                    s.fx.resize(k);
+                    s.fy.resize(k);
+                }
                 bool refit = false;
                 if ((int)members.size() > c.p.min_tags_to_curve_fit) {
                     fit_members(arc, s);
@@ -984,12 +1067,21 @@ private:
                 }
                 if (refit) {
                     const size_t nm = members.size();
-                    for (size_t i = 0; i < nm; ++i)
-                        if (farther_than_maxd(
-                                dist_sq(arc, s.mf[i], s.mx[i], s.my[i]))) {
-                            bad = true;
-                            break;
-                        }
+                    if (simd_) {
+                        const double p5[5] = {arc.a, arc.b, arc.c, arc.e,
+                                              arc.f_peak};
+                        bad = simd_any_farther(p5, rot_.s, rot_.c,
+                                               s.mf.data(), s.mx.data(),
+                                               s.my.data(), nm, maxd_,
+                                               maxd_sq_lo_, maxd_sq_hi_);
+                    } else {
+                        for (size_t i = 0; i < nm; ++i)
+                            if (farther_than_maxd(
+                                    dist_sq(arc, s.mf[i], s.mx[i], s.my[i]))) {
+                                bad = true;
+                                break;
+                            }
+                    }
                 }
                 // without a refit the arc is unchanged: the older members
                 // passed this test already and the new one has
@@ -1008,6 +1100,12 @@ private:
             }
         }
     }
+
+    struct TagRec {                 // what the growth loop reads per tag
+        double x, y;
+        int frame, qpos;
+    };
+    std::vector<TagRec> tag_;
 
     hk_clip &c_;
     const int n_;
@@ -1039,6 +1137,10 @@ private:
     std::atomic<unsigned> generation_{0};
     std::atomic<bool> quit_{false}, stop_{false};
     int nthreads_ = 1;
+    // HK_STEP3_SIMD=0: the scalar loops (tests compare the two)
+    const bool simd_ = simd_available() &&
+                       !(getenv("HK_STEP3_SIMD") &&
+                         atoi(getenv("HK_STEP3_SIMD")) == 0);
     bool has_vmax_ = false;
     double v_max_ = 0, maxd_ = 0, maxd_sq_lo_ = 0, maxd_sq_hi_ = 0, e0_ = 0;
     Rot rot_{0, 1};

@@ -134,3 +134,7 @@ def test_result_does_not_depend_on_thread_count_or_window(monkeypatch):
     assert len(want[2]) > 20
     for threads, window in ((2, 1), (4, 16), (8, 256), (16, 1024), (3, 7)):
         assert run(threads, window) == want, (threads, window)
+    # the AVX2 member / frontier loops against the scalar ones
+    monkeypatch.setenv('HK_STEP3_SIMD', '0')
+    assert run(1, 16) == want
+    assert run(4, 64) == want
