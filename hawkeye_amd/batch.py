@@ -32,6 +32,28 @@ from .arcs import Clip, scan_params
 from .detect import EventDetector, hawkeye_blob_params
 
 
+def host_core_share():
+    """Host cores this process may plan on: the cores it is allowed to run on,
+    divided among the ranks of the node (one process per GPU), capped by
+    OMP_NUM_THREADS (the GPU boxes export their CPU share there) and by 16.
+    torch.distributed.run exports OMP_NUM_THREADS=1 to every rank when the
+    variable was unset; with several local ranks a value of 1 is taken to be
+    that default, not a statement about the machine."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))
+    share = max(1, avail // ranks)
+    try:
+        omp = int(os.environ.get('OMP_NUM_THREADS', '0') or 0)
+    except ValueError:
+        omp = 0
+    if omp > 1 or (omp == 1 and ranks == 1):
+        share = min(share, omp)
+    return max(1, min(share, 16))
+
+
 class ClipResult:
     """Events and arcs of one clip.
 
@@ -250,9 +272,7 @@ class ClipScanner:
 
         # leave cores to the detection loop and to step 4 while step 3 runs
         if host_threads is None:
-            cores = min(os.cpu_count() or 1,
-                        int(os.environ.get('OMP_NUM_THREADS', '16')), 16)
-            host_threads = max(1, (cores - 2) // builders)
+            host_threads = max(1, (host_core_share() - 2) // builders)
         nat.check(nat.lib.hk_set_host_threads(int(host_threads)))
         workers = [threading.Thread(target=detect_stage, daemon=True)] + \
             [threading.Thread(target=build_stage, daemon=True)

@@ -185,7 +185,18 @@ int worker_count() {
     const int forced = g_host_threads.load();
     if (forced > 0) n = forced;
     else if (const char *e = getenv("HK_THREADS")) n = atoi(e);
-    else if (const char *o = getenv("OMP_NUM_THREADS")) n = std::min(n, atoi(o));
+    else {
+        // one process per GPU: the node's cores are shared by its ranks.
+        // torch.distributed.run exports OMP_NUM_THREADS=1 when the variable
+        // was unset; with several local ranks 1 is taken to be that default.
+        int ranks = 1;
+        if (const char *r = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(r));
+        n = std::max(1, n / ranks);
+        if (const char *o = getenv("OMP_NUM_THREADS")) {
+            const int omp = atoi(o);
+            if (omp > 1 || (omp == 1 && ranks == 1)) n = std::min(n, omp);
+        }
+    }
     return std::max(1, std::min(n, 16));
 }
 
