@@ -136,17 +136,18 @@ def traffic_from_profiles():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--frames', type=int, default=None,
                     help='shorter clip (debugging only; invalidates value)')
     ap.add_argument('--cpu-sample', type=int, default=96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=None,
-                    help='step-3 worker threads in the pipelined run '
-                         '(default: host cores - 2, at most 14)')
-    ap.add_argument('--builders', type=int, default=2,
-                    help='clips in step 3 at the same time (pipelined run)')
+                    help='step-3 worker threads per clip in the pipelined '
+                         'run (default: ClipScanner.plan_host_stage)')
+    ap.add_argument('--builders', type=int, default=None,
+                    help='clips in step 3 at the same time (pipelined run; '
+                         'default: ClipScanner.plan_host_stage)')
     ap.add_argument('--host-frames', type=int, default=512,
                     help='frames of the PCIe-inclusive side measurement '
                          '(0 = skip)')
@@ -198,7 +199,8 @@ def main():
     t0 = time.perf_counter()
     for result in scanner.scan_many((frames for _ in range(args.steps)),
                                     host_threads=args.host_threads,
-                                    builders=args.builders):
+                                    builders=args.builders,
+                                    count=args.steps):
         for k in stage_s:
             stage_s[k] += result.stage_seconds[k]
     barrier()
