@@ -221,11 +221,25 @@ inline void cpu_relax() {
 //
 // There is no barrier: workers run up to `window_` seeds ahead of the commit
 // position through a ring of result slots.
+#ifdef HK_S3_PROF
+#include <x86intrin.h>
+struct S3Prof { unsigned long long cyc[8] = {0}, cnt[8] = {0}; };
+static S3Prof g_s3prof;         // single-thread measurements only
+#define S3P_T0 const unsigned long long s3p_t0 = __rdtsc()
+#define S3P_ADD(k) do { g_s3prof.cyc[k] += __rdtsc() - s3p_t0; ++g_s3prof.cnt[k]; } while (0)
+#define S3P_CNT(k, n) (g_s3prof.cnt[k] += (n))
+#else
+#define S3P_T0 do {} while (0)
+#define S3P_ADD(k) do {} while (0)
+#define S3P_CNT(k, n) do {} while (0)
+#endif
+
 class ArcBuilder {
 public:
     explicit ArcBuilder(hk_clip &c)
         : c_(c), n_(c.n), queue_((size_t)c.n), qpos_((size_t)c.n),
           nb_ptr_((size_t)c.n, nullptr), nb_len_((size_t)c.n, 0),
+          grp_ptr_((size_t)c.n, nullptr), grp_len_((size_t)c.n, 0),
           nb_state_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           done_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
           taken_(new std::atomic<uint8_t>[c.n ? c.n : 1]),
@@ -822,10 +836,29 @@ private:
                              });
         }
         const size_t m = s.cand.size();
-        int *out = m ? s.pool_alloc(m) : nullptr;
+        // both branches met the candidates frame by frame, in ascending order
+        size_t groups = 0;
+        for (size_t k = 0; k < m; ++k)
+            if (k == 0 || c.frame[s.cand[k]] != c.frame[s.cand[k - 1]])
+                ++groups;
+        int *out = m ? s.pool_alloc(2 * m + 2 * groups) : nullptr;
         for (size_t k = 0; k < m; ++k) out[k] = s.cand[(size_t)s.order[k]];
+        int *grp = out + m, *count = nullptr;
+        size_t w = 0;
+        for (size_t k = 0; k < m; ++k) {
+            const int j = s.cand[k];
+            if (k == 0 || c.frame[j] != c.frame[s.cand[k - 1]]) {
+                grp[w++] = c.frame[j];
+                count = &grp[w++];
+                *count = 0;
+            }
+            grp[w++] = j;
+            ++*count;
+        }
         nb_ptr_[(size_t)i] = out;
         nb_len_[(size_t)i] = (int)m;
+        grp_ptr_[(size_t)i] = grp;
+        grp_len_[(size_t)i] = (int)w;
     }
 
     static void consult(int j, Scratch &s, SeedResult &res) {
@@ -843,7 +876,19 @@ private:
     void add_neighbors_to_frontier(int i, int pos, Scratch &s,
                                    SeedResult &res) {
         if (has_vmax_) {
-            add_to_frontier(neighbors(i, s), pos, s, res);
+            // frames the arc already has a tag in are skipped as a whole: a
+            // growing arc has taken most of the frames behind its new member
+            neighbors(i, s);
+            const int *p = grp_ptr_[(size_t)i];
+            const int *const end = p + grp_len_[(size_t)i];
+            while (p < end) {
+                const int g = p[0], k = p[1];
+                p += 2;
+                if (s.taken[g] != s.stamp)
+                    for (int q = 0; q < k; ++q)
+                        add_one_to_frontier(p[q], pos, s, res);
+                p += k;
+            }
             return;
         }
         const hk_clip &c = c_;
@@ -858,10 +903,6 @@ private:
     void add_range_to_frontier(int j0, int j1, int pos, Scratch &s,
                                SeedResult &res) {
         for (int j = j0; j < j1; ++j) add_one_to_frontier(j, pos, s, res);
-    }
-
-    void add_to_frontier(Span src, int pos, Scratch &s, SeedResult &res) {
-        for (int j : src) add_one_to_frontier(j, pos, s, res);
     }
 
     void add_one_to_frontier(int j, int pos, Scratch &s, SeedResult &res) {
@@ -948,10 +989,12 @@ private:
         res.made = false;
         res.consulted.clear();
         ++s.run_stamp;
-        const Span nb1 = neighbors(t1, s);
+        Span nb1;
+        { S3P_T0; nb1 = neighbors(t1, s); S3P_ADD(5); }
         for (int t2 : nb1) {
             if (is_done(t2, pos)) continue;
             consult(t2, s, res);
+            S3P_CNT(7, 1);
             ++s.stamp;
             Arc arc;
             const int f1 = c.frame[t1], f2 = c.frame[t2];
@@ -973,8 +1016,10 @@ private:
             s.ff.clear();
             s.fx.clear();
             s.fy.clear();
-            add_to_frontier(nb1, pos, s, res);
+            { S3P_T0;
+            add_neighbors_to_frontier(t1, pos, s, res);
             add_neighbors_to_frontier(t2, pos, s, res);
+            S3P_ADD(0); }
 
             arc.e = e0_;
             arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
@@ -993,6 +1038,8 @@ private:
                 // equals.  Compared on squared distances; the roots are only
                 // taken among those within rounding of the smallest.
                 const size_t nf = s.frontier.size();
+                S3P_CNT(6, nf);
+                S3P_T0;
                 s.fq.resize(nf);
                 double q_min = 0;
                 if (simd_) {
@@ -1036,6 +1083,7 @@ private:
                         }
                     }
                 }
+                S3P_ADD(1);
                 if (best_d > maxd_) break;
                 const size_t at = (size_t)(
                     std::upper_bound(members.begin(), members.end(), best) -
@@ -1046,7 +1094,9 @@ private:
                 s.mx.insert(s.mx.begin() + (long)at, tb.x);
                 s.my.insert(s.my.begin() + (long)at, tb.y);
                 s.taken[tb.frame] = s.stamp;
+                { S3P_T0;
                 add_neighbors_to_frontier(best, pos, s, res);
+                S3P_ADD(2); }
                 {   // drop the frontier tags of the frame just taken (the
                     // only frame that became taken; order is kept)
                     const double fb = (double)tb.frame;
@@ -1069,7 +1119,9 @@ private:
                 }
                 bool refit = false;
                 if ((int)members.size() > c.p.min_tags_to_curve_fit) {
+                    S3P_T0;
                     fit_members(arc, s);
+                    S3P_ADD(3);
                     refit = true;
                 }
                 if (std::isnan(arc.e) || arc.e <= 0) {
@@ -1077,6 +1129,7 @@ private:
                     break;
                 }
                 if (refit) {
+                    S3P_T0;
                     const size_t nm = members.size();
                     if (simd_) {
                         const double p5[5] = {arc.a, arc.b, arc.c, arc.e,
@@ -1093,6 +1146,7 @@ private:
                                 break;
                             }
                     }
+                    S3P_ADD(4);
                 }
                 // without a refit the arc is unchanged: the older members
                 // passed this test already and the new one has
@@ -1131,6 +1185,10 @@ private:
     bool x_index_ok_ = false;
     std::vector<const int *> nb_ptr_;
     std::vector<int> nb_len_;
+    // the same neighbours grouped by frame: {frame, count, tags...} per
+    // frame that has any (what the frontier is fed from)
+    std::vector<const int *> grp_ptr_;
+    std::vector<int> grp_len_;
     std::unique_ptr<std::atomic<uint8_t>[]> nb_state_;
     std::unique_ptr<std::atomic<uint8_t>[]> done_;
     std::unique_ptr<std::atomic<uint8_t>[]> taken_;  // member of an accepted arc
@@ -1719,6 +1777,17 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
                     ms(t0, t1), ms(t1, now()), b.stat_stale_, b.stat_stale_ms_,
                     b.stat_helped_, b.stat_busy_ms_, b.stat_dev_used_.load(),
                     b.stat_dev_host_.load());
+#ifdef HK_S3_PROF
+        if (stats) {
+            static const char *nm[8] = {"frontier init", "distance scan + min",
+                "frontier add (growth)", "fit", "member check", "seed nb list",
+                "frontier tags scanned", "trials"};
+            for (int k = 0; k < 8; ++k)
+                fprintf(stderr, "  s3prof %-24s %8.2f Mcyc  n=%llu\n", nm[k],
+                        hk::g_s3prof.cyc[k] / 1e6, hk::g_s3prof.cnt[k]);
+            hk::g_s3prof = hk::S3Prof();
+        }
+#endif
     }
     std::stable_sort(arcs.begin(), arcs.end(), [](const Arc &p, const Arc &q) {
         return p.f_peak < q.f_peak;
