@@ -87,3 +87,32 @@ def test_pack_roundtrip_and_order_check():
     with pytest.raises(ValueError):
         hk.unpack_events(rec[::-1], 30)
     assert hk.unpack_events(np.zeros((0, 4), np.int32), 3)[2].shape == (0, 3)
+
+
+def test_host_core_share_and_stage_plan(monkeypatch):
+    """A rank plans on its share of the node's cores; torch.distributed.run's
+    default OMP_NUM_THREADS=1 is not taken as the machine's size."""
+    from hawkeye_amd import batch
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(128)),
+                        raising=False)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setenv('OMP_NUM_THREADS', '1')
+    assert batch.host_core_share() == 16
+    monkeypatch.setenv('OMP_NUM_THREADS', '12')
+    assert batch.host_core_share() == 12
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    monkeypatch.setenv('OMP_NUM_THREADS', '1')
+    assert batch.host_core_share() == 1
+    monkeypatch.delenv('OMP_NUM_THREADS')
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(6)),
+                        raising=False)
+    assert batch.host_core_share() == 6
+    plan = batch.ClipScanner.plan_host_stage
+    assert plan(None, cores=16) == (14, 1)
+    assert plan(80, cores=16) == (14, 1)
+    assert plan(20, cores=16) == (7, 2)
+    assert plan(4, cores=16) == (2, 7)
+    for count in (None, 1, 20, 100):
+        for cores in (1, 2, 3, 8, 16):
+            b, t = plan(count, cores=cores)
+            assert b >= 1 and t >= 1 and b * t <= max(1, cores - 2)
