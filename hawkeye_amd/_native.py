@@ -147,6 +147,9 @@ _sig('hk_clip_eval_arc', [C.c_void_p, C.c_int, C.c_int, C.c_int])
 _sig('hk_clip_member_distances', [C.c_void_p, C.c_void_p, C.c_void_p])
 
 
+HK_ERR_CAPACITY = -3        # include/hk.h
+
+
 def check(status):
     """Raise NativeError for a negative status, else return the status."""
     if status < 0:

@@ -52,7 +52,8 @@ namespace {
 constexpr int MAXPTS = 256;             // hard cap on a traced contour
 constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
 constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
-constexpr unsigned BAND_CAP = 2048;     // candidates per (frame, band)
+constexpr unsigned BAND_CAP0 = 2048;    // candidates per (frame, band) to
+                                        // start with; grown on demand
 constexpr int TRACE_LDS_BYTES = 128 * 1024;
 
 struct Cand {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
     int H, int nframes, int segs, bool vec, Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, int band_rows, int nbands,
-    unsigned short *__restrict__ bits, int words_per_row) {
+    unsigned short *__restrict__ bits, int words_per_row, unsigned band_cap) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)nframes * H * segs;
     if (tid >= total) return;
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     if (c == 0) return;
     const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
-    if (at + c > BAND_CAP) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
-    Cand *list = cands + (size_t)bucket * BAND_CAP;
+    if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
+    Cand *list = cands + (size_t)bucket * band_cap;
     while (outer) {
         const int i = __ffs(outer) - 1;
         outer &= outer - 1;
-        if (at < BAND_CAP)
+        if (at < band_cap)
             list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i),
                             (unsigned)f << 1};
         ++at;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     while (hole) {
         const int i = __ffs(hole) - 1;
         hole &= hole - 1;
-        if (at < BAND_CAP)      // origin = the foreground pixel left of it
+        if (at < band_cap)      // origin = the foreground pixel left of it
             list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
                             ((unsigned)f << 1) | 1u};
         ++at;
@@ -318,12 +319,13 @@ __global__ __launch_bounds__(256) void blob_trace_k(
     const uint32_t *__restrict__ bits, int words_per_row, int W,
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
-    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm) {
+    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm,
+    unsigned band_cap) {
     extern __shared__ uint32_t band_lds[];
     const unsigned bucket = blockIdx.x;
     unsigned n = ctr[CTR_WORDS + bucket];
     if (n == 0) return;                     // workgroup-uniform
-    if (n > BAND_CAP) n = BAND_CAP;
+    if (n > band_cap) n = band_cap;
     const int frame = (int)(bucket / (unsigned)nbands);
     const int band = (int)(bucket % (unsigned)nbands);
     // image rows band*band_rows - 1 .. + band_rows + max_pts/2 + 1
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void blob_trace_k(
     const BandImg img{band_lds, words_per_row, row0, fbits, W, H};
 
     for (unsigned i = threadIdx.x; i < n; i += 256) {
-        const Cand c = cands[(size_t)bucket * BAND_CAP + i];
+        const Cand c = cands[(size_t)bucket * band_cap + i];
         const int x0 = (int)(c.pos & 0xFFFFu), y0 = (int)(c.pos >> 16);
         const bool hole = (c.fh & 1u) != 0u;
 
@@ -562,6 +564,16 @@ struct hk_blob {
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;
     int pending_frames = 0;             // batch between enqueue and finish
+    unsigned band_cap = BAND_CAP0;      // entries per (frame, band) in cands
+    // the batch in flight (collect() runs it again with larger buffers if
+    // a list overflowed)
+    const uint8_t *masks = nullptr;
+    long frame_stride = 0, pitch = 0;
+    std::vector<unsigned> h_counts;     // per-band candidate counts
+    // contours of a finished batch whose results did not fit the caller's
+    // buffer: handed out by the next hk_blob_finish*() call
+    std::vector<std::vector<Center>> held;
+    bool has_held = false;
 };
 
 extern "C" int hk_blob_params_hawkeye(hk_blob_params *p, int scan_height) {
@@ -674,7 +686,7 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     b->eager = std::min(b->cap_blob, (unsigned)max_frames * 48u);
 
     hipError_t e = hipMalloc((void **)&b->cands,
-                             sizeof(Cand) * BAND_CAP * nbuckets);
+                             sizeof(Cand) * b->band_cap * nbuckets);
     if (e == hipSuccess)        // counters, then one candidate count per band
         e = hipMalloc((void **)&b->ctr,
                       sizeof(unsigned) * (CTR_WORDS + nbuckets));
@@ -707,6 +719,41 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     return HK_OK;
 }
 
+// The kernels of the batch b->masks / nframes on b->stream (device current).
+static int launch_batch(hk_blob *b, int nframes) {
+    const hipStream_t s = b->stream;
+    const uint8_t *masks = b->masks;
+    const long frame_stride = b->frame_stride, pitch = b->pitch;
+
+    const unsigned nbuckets = (unsigned)nframes * b->nbands;
+    HK_HIP(hipMemsetAsync(b->ctr, 0,
+                          sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
+    const int segs = (b->width + 15) / 16;
+    const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
+                     (nframes == 1 || frame_stride % 16 == 0);
+    const long total = (long)nframes * b->height * segs;
+    hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, s, masks, frame_stride, pitch, b->width,
+                       b->height, nframes, segs, vec, b->cands, b->ctr,
+                       b->band_rows, b->nbands, (unsigned short *)b->bits,
+                       b->words_per_row, b->band_cap);
+    HK_LAUNCH_CHECK("blob_scan_k");
+    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(256), b->trace_lds,
+                       s, b->bits, b->words_per_row, b->width, b->height,
+                       b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
+                       b->pts, b->cap_blob, b->dev, b->band_cap);
+    HK_LAUNCH_CHECK("blob_trace_k");
+    hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
+                       b->cap_blob, b->recs, b->pts);
+    HK_LAUNCH_CHECK("blob_radius_k");
+    HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
+                          hipMemcpyDeviceToHost, s));
+    HK_HIP(hipMemcpyAsync(b->h_recs, b->recs, sizeof(BlobRec) * b->eager,
+                          hipMemcpyDeviceToHost, s));
+    HK_HIP(hipEventRecord(b->done, s));
+    return HK_OK;
+}
+
 extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
                                long frame_stride, long pitch, int nframes,
                                void *stream) {
@@ -723,37 +770,57 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
         return hk::fail(HK_ERR_ARG,
                         "hk_blob_enqueue: previous batch not finished");
     hk::DeviceGuard guard(b->device);
-    const hipStream_t s = (hipStream_t)stream;
-    const uint8_t *masks = (const uint8_t *)mask_dev;
-
-    const unsigned nbuckets = (unsigned)nframes * b->nbands;
-    HK_HIP(hipMemsetAsync(b->ctr, 0,
-                          sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
-    const int segs = (b->width + 15) / 16;
-    const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
-                     (nframes == 1 || frame_stride % 16 == 0);
-    const long total = (long)nframes * b->height * segs;
-    hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
-                       dim3(256), 0, s, masks, frame_stride, pitch, b->width,
-                       b->height, nframes, segs, vec, b->cands, b->ctr,
-                       b->band_rows, b->nbands, (unsigned short *)b->bits,
-                       b->words_per_row);
-    HK_LAUNCH_CHECK("blob_scan_k");
-    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(256), b->trace_lds,
-                       s, b->bits, b->words_per_row, b->width, b->height,
-                       b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
-                       b->pts, b->cap_blob, b->dev);
-    HK_LAUNCH_CHECK("blob_trace_k");
-    hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
-                       b->cap_blob, b->recs, b->pts);
-    HK_LAUNCH_CHECK("blob_radius_k");
-    HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipMemcpyAsync(b->h_recs, b->recs, sizeof(BlobRec) * b->eager,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipEventRecord(b->done, s));
-    b->stream = s;
+    b->has_held = false;
+    b->held.clear();
+    b->stream = (hipStream_t)stream;
+    b->masks = (const uint8_t *)mask_dev;
+    b->frame_stride = frame_stride;
+    b->pitch = pitch;
+    const int rc = launch_batch(b, nframes);
+    if (rc != HK_OK) return rc;
     b->pending_frames = nframes;
+    return HK_OK;
+}
+
+// Grows the candidate lists (to the largest per-band count of the batch) and
+// the contour buffers (4x: how many contours pass the filters is only known
+// once every candidate has been traced), then runs the batch again.
+static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
+    const size_t nbuckets_max = (size_t)b->max_frames * b->nbands;
+    HK_HIP(hipStreamSynchronize(b->stream));
+    if (band_full) {
+        const size_t nb = (size_t)nframes * b->nbands;
+        b->h_counts.resize(nb);
+        HK_HIP(hipMemcpy(b->h_counts.data(), b->ctr + CTR_WORDS,
+                         sizeof(unsigned) * nb, hipMemcpyDeviceToHost));
+        unsigned need = 0;
+        for (unsigned v : b->h_counts) need = std::max(need, v);
+        unsigned cap = b->band_cap;
+        while (cap < need) cap *= 2;
+        (void)hipFree(b->cands);
+        b->cands = nullptr;
+        b->band_cap = cap;
+        HK_HIP(hipMalloc((void **)&b->cands,
+                         sizeof(Cand) * (size_t)cap * nbuckets_max));
+    }
+    if (b->h_ctr[CTR_NBLOB] > b->cap_blob) {
+        unsigned cap = b->cap_blob;
+        while (cap < b->h_ctr[CTR_NBLOB]) cap *= 4;
+        (void)hipFree(b->recs);
+        (void)hipFree(b->pts);
+        (void)hipHostFree(b->h_recs);
+        b->recs = nullptr;
+        b->pts = nullptr;
+        b->h_recs = nullptr;
+        b->cap_blob = cap;
+        HK_HIP(hipMalloc((void **)&b->recs, sizeof(BlobRec) * cap));
+        HK_HIP(hipMalloc((void **)&b->pts,
+                         sizeof(ushort2) * MAXPTS * (size_t)cap));
+        HK_HIP(hipHostMalloc((void **)&b->h_recs, sizeof(BlobRec) * cap));
+    }
+    const int rc = launch_batch(b, nframes);
+    if (rc != HK_OK) return rc;
+    HK_HIP(hipEventSynchronize(b->done));
     return HK_OK;
 }
 
@@ -761,24 +828,35 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
 // order findContours(RETR_LIST) lists them (reverse discovery order).
 static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
     if (!b) return hk::fail(HK_ERR_ARG, "hk_blob_finish: null handle");
+    if (!b->pending_frames && b->has_held) {
+        frames.swap(b->held);
+        b->has_held = false;
+        return HK_OK;
+    }
     if (!b->pending_frames)
         return hk::fail(HK_ERR_ARG, "hk_blob_finish: nothing enqueued");
+    b->has_held = false;
     hk::DeviceGuard guard(b->device);
     const int nframes = b->pending_frames;
     b->pending_frames = 0;
     HK_HIP(hipEventSynchronize(b->done));
-    const unsigned nblob = b->h_ctr[CTR_NBLOB];
     if (b->h_ctr[CTR_FLAGS] & FLAG_NONBINARY)
         return hk::fail(HK_ERR_ARG,
                         "hk_blob: mask holds values other than 0 and 255");
-    if (b->h_ctr[CTR_FLAGS] & FLAG_BAND_FULL)
-        return hk::fail(HK_ERR_CAPACITY,
-                        "hk_blob: more than %u border candidates in a band "
-                        "of %d rows", BAND_CAP, b->band_rows);
-    if (nblob > b->cap_blob)
-        return hk::fail(HK_ERR_CAPACITY,
-                        "hk_blob: %u contours exceed capacity %u", nblob,
-                        b->cap_blob);
+    // A list that overflowed (very noisy masks): the counters hold the sizes
+    // that were needed, so the buffers grow to those and the batch runs once
+    // more.  The buffers keep their size afterwards.
+    for (int pass = 0; pass < 3; ++pass) {
+        const bool band_full = (b->h_ctr[CTR_FLAGS] & FLAG_BAND_FULL) != 0;
+        const bool blob_full = b->h_ctr[CTR_NBLOB] > b->cap_blob;
+        if (!band_full && !blob_full) break;
+        if (pass == 2)
+            return hk::fail(HK_ERR_INTERNAL,
+                            "hk_blob: work lists still full after growing");
+        const int rc = grow_and_rerun(b, nframes, band_full);
+        if (rc != HK_OK) return rc;
+    }
+    const unsigned nblob = b->h_ctr[CTR_NBLOB];
     if (nblob > b->eager) {
         HK_HIP(hipMemcpyAsync(b->h_recs + b->eager, b->recs + b->eager,
                               sizeof(BlobRec) * (nblob - b->eager),
@@ -826,9 +904,12 @@ extern "C" int hk_blob_finish_centers(hk_blob *b, int *counts_host,
         }
     }
     *total = n;
-    if (n > cap)
+    if (n > cap) {
+        b->held.swap(frames);
+        b->has_held = true;
         return hk::fail(HK_ERR_CAPACITY, "hk_blob: %d centres, capacity %d",
                         n, cap);
+    }
     return HK_OK;
 }
 
@@ -851,9 +932,12 @@ extern "C" int hk_blob_finish(hk_blob *b, int *counts_host, float *kp_host,
                                      3 * sizeof(float));
     }
     *total = n;
-    if (n > cap)
+    if (n > cap) {
+        b->held.swap(frames);
+        b->has_held = true;
         return hk::fail(HK_ERR_CAPACITY, "hk_blob: %d keypoints, capacity %d",
                         n, cap);
+    }
     return HK_OK;
 }
 

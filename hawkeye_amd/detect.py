@@ -172,21 +172,29 @@ class SimpleBlobDetector:
         self._keep = None
         return out
 
-    def finish(self):
+    def _finish_into(self, fn, name, dtype):
+        """Calls hk_blob_finish*(); a batch with more results than the output
+        array holds is kept by the library and fetched again into a larger
+        one (OpenCV has no limit on the number of keypoints)."""
         total = nat.C.c_int()
-        nat.check(nat.lib.hk_blob_finish(
-            self._h, self._counts.ctypes.data, self._kp.ctypes.data,
-            self._cap, nat.C.byref(total)))
-        return self._split(self._kp, total.value)
+        for _ in range(2):
+            buf = getattr(self, name)
+            status = fn(self._h, self._counts.ctypes.data, buf.ctypes.data,
+                        len(buf), nat.C.byref(total))
+            if status != nat.HK_ERR_CAPACITY or total.value <= len(buf):
+                break
+            setattr(self, name, np.empty((2 * total.value, 3), dtype))
+        nat.check(status)
+        return self._split(getattr(self, name), total.value)
+
+    def finish(self):
+        return self._finish_into(nat.lib.hk_blob_finish, '_kp', np.float32)
 
     def finish_centers(self):
         """Per-contour stage only: float64 [n][3] (x, y, radius) per frame,
         what one findBlobs() pass yields.  For tests."""
-        total = nat.C.c_int()
-        nat.check(nat.lib.hk_blob_finish_centers(
-            self._h, self._counts.ctypes.data, self._centers.ctypes.data,
-            self._cap, nat.C.byref(total)))
-        return self._split(self._centers, total.value)
+        return self._finish_into(nat.lib.hk_blob_finish_centers, '_centers',
+                                 np.float64)
 
     def detect(self, masks):
         masks = self._check_masks(masks)

@@ -136,13 +136,18 @@ int hk_blob_create(int width, int height, int max_frames,
 int hk_blob_destroy(hk_blob *b);
 
 /* Enqueue detection on `nframes` masks (mask t at mask_dev + t*frame_stride,
- * rows `pitch` bytes apart) on `stream`.  Returns immediately. */
+ * rows `pitch` bytes apart) on `stream`.  Returns immediately.  The masks
+ * must stay valid and unchanged until hk_blob_finish() returns: a batch whose
+ * work lists overflow (very noisy masks) is run again there with larger
+ * lists, as OpenCV has no limit on the number of contours. */
 int hk_blob_enqueue(hk_blob *b, const void *mask_dev, long frame_stride,
                     long pitch, int nframes, void *stream);
 /* Wait for the enqueued batch and finish on the host (ordering, radius,
  * grouping).  counts_host[t] = keypoints of frame t; kp_host receives
  * (x, y, size) float triples, frame after frame; *total = sum of counts.
- * HK_ERR_CAPACITY if total > cap (nothing beyond cap is written). */
+ * HK_ERR_CAPACITY if total > cap: nothing beyond cap is written, *total holds
+ * the size needed, and the batch's results are kept until the next
+ * hk_blob_finish*() call (with a larger buffer) or the next enqueue. */
 int hk_blob_finish(hk_blob *b, int *counts_host, float *kp_host, int cap,
                    int *total);
 /* hk_blob_enqueue + hk_blob_finish. */

@@ -113,6 +113,28 @@ def test_pure_noise_and_extremes():
     check_against_oracle(masks, params_height=300)
 
 
+def test_dense_noise_grows_the_work_lists():
+    """More border candidates in a band of rows, and more surviving contours,
+    than the work lists start with (2048 per band, 128 per frame): the
+    detector grows them and runs the batch again; a sparse batch afterwards
+    still works."""
+    rng = np.random.RandomState(31)
+    h, w = 160, 1920
+    dense = np.stack(
+        [(rng.uniform(size=(h, w)) < d).astype(np.uint8) * 255
+         for d in (0.05, 0.2)] +
+        [mask_smooth_noise(rng, h, w, 5, 0.52)])
+    check_against_oracle(dense)
+    from hawkeye_amd.detect import SimpleBlobDetector, hawkeye_blob_params
+    from oracle import detect_ref as D
+    det = SimpleBlobDetector(w, h, params=hawkeye_blob_params(h), max_frames=2)
+    sparse = mask_shapes(rng, h, w, n_discs=10, specks=5, big=False)
+    for m in (dense[1], sparse, dense[2], sparse):
+        got = det.detect(torch.from_numpy(m[None]).cuda())[0]
+        want = D.blob_detect(m, D.hawkeye_params(h))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_full_hd_sparse_blobs():
     rng = np.random.RandomState(23)
     h, w = 1080, 1920
