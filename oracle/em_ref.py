@@ -32,6 +32,14 @@ from statistics import median
 
 import numpy as np
 
+# The reference writes t**3, t**4 and T2**3 (tracker.py:729-730, 757), i.e.
+# pow(); the native code multiplies.  The two differ by at most one ulp, far
+# inside the reference's own run-to-run variation (it sums in set order), but
+# while a trial arc's peak lies hundreds of frames from its tags the fit is
+# ill-conditioned enough to turn that ulp into a different arc set.  The
+# randomised comparison (tests/fuzz_arcs.py) sets this to take that noise out.
+POWERS_AS_PRODUCTS = False
+
 G_CM = 980.7
 
 
@@ -151,7 +159,11 @@ class Scene:
             w = weight_of(i)
             x, y = self.x[i], self.y[i]
             T0 += w; T1 += w * t; T2 += w * t**2
-            T3 += w * t**3; T4 += w * t**4
+            if POWERS_AS_PRODUCTS:
+                t2 = t * t
+                T3 += w * (t2 * t); T4 += w * (t2 * t2)
+            else:
+                T3 += w * t**3; T4 += w * t**4
             X1 += w * x; TX += w * t * x; T2X += w * t**2 * x
             Y1 += w * y; TY += w * t * y; T2Y += w * t**2 * y
         return T0, T1, T2, T3, T4, X1, TX, T2X, Y1, TY, T2Y
@@ -165,7 +177,8 @@ class Scene:
             self._moments(arc, weight_of)
         s, c = math.sin(self.tilt), math.cos(self.tilt)
         det2 = T0 * T2 - T1**2
-        det3 = 2*T1*T2*T3 + T0*T2*T4 - T0*T3**2 - T1**2*T4 - T2**3
+        det3 = 2*T1*T2*T3 + T0*T2*T4 - T0*T3**2 - T1**2*T4 - \
+            (T2 * T2 * T2 if POWERS_AS_PRODUCTS else T2**3)
         if abs(det2) < 1e-3 or abs(det3) < 1e-3:
             return
         bx1 = c * TX - s * TY

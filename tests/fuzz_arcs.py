@@ -31,6 +31,7 @@ from hawkeye_amd.arcs import Clip                           # noqa: E402
 from oracle import em_ref                                   # noqa: E402
 
 REL = 1e-6
+em_ref.POWERS_AS_PRODUCTS = True    # round like the native code (see there)
 
 
 def close(a, b, rel=REL, abs_=1e-9):
@@ -49,7 +50,7 @@ def random_case(rng):
     meas = synth.make_tags(scene, int(rng.randint(1 << 30)),
                            clutter_per_frame=float(rng.choice([0, 2, 6, 14])),
                            detect_prob=float(rng.choice([1.0, 0.92, 0.7])),
-                           pos_sigma=float(rng.choice([0.0, 0.6, 2.0])))
+                           pos_sigma=float(rng.choice([0.3, 0.6, 2.0])))
     for d in range(int(rng.choice([0, 0, 3]))):     # slow distractor tracks
         px, py = rng.uniform(0, w), rng.uniform(0, h)
         for f in range(frames):
