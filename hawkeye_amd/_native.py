@@ -66,6 +66,9 @@ _sig('hk_mog_apply', [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
 _sig('hk_mog_apply_batch', [C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                             C.c_void_p, C.c_long, C.c_long, C.c_int,
                             C.c_void_p])
+_sig('hk_mog_tiles_supported', [C.c_void_p])
+_sig('hk_mog_apply_batch_tiles', [C.c_void_p, C.c_void_p, C.c_long, C.c_long,
+                                  C.c_void_p, C.c_int, C.c_void_p])
 _sig('hk_mog_export_model', [C.c_void_p, C.c_void_p, C.c_void_p])
 
 
@@ -88,6 +91,9 @@ _sig('hk_blob_create', [C.c_int, C.c_int, C.c_int, C.POINTER(BlobParams),
 _sig('hk_blob_destroy', [C.c_void_p])
 _sig('hk_blob_enqueue', [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int,
                          C.c_void_p])
+_sig('hk_blob_tiles_buffer', [C.c_void_p, C.POINTER(C.c_void_p),
+                              C.POINTER(C.c_long)])
+_sig('hk_blob_enqueue_tiles', [C.c_void_p, C.c_int, C.c_void_p])
 _sig('hk_blob_finish', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                         C.POINTER(C.c_int)])
 _sig('hk_blob_detect', [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int,

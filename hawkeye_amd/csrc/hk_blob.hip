@@ -185,6 +185,88 @@ __global__ __launch_bounds__(256) void blob_scan_k(
 }
 
 // ---------------------------------------------------------------------------
+// K2 fed by the MOG kernel's 1-bit tiles (hk_mog_apply_batch_tiles): per
+// 32 x 4 pixel tile and frame four words, the foreground bits of the tile's
+// even pixels (lane order: 16 per row) and of its odd pixels.  blob_untile_k
+// interleaves them into the padded 1-bit image, blob_scan_bits_k finds the
+// candidate border starts on whole words -- 1/8 of the bytes blob_scan_k reads.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned spread16(unsigned v) {  // bit i -> bit 2i
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void blob_untile_k(
+    const uint32_t *__restrict__ tiles, int tiles_x, int tiles_y, int nframes,
+    int H, uint32_t *__restrict__ bits, int words_per_row) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)nframes * H * tiles_x;
+    if (tid >= total) return;
+    const int wx = (int)(tid % tiles_x);
+    const long fy = tid / tiles_x;
+    const int y = (int)(fy % H);
+    const int f = (int)(fy / H);
+    const uint32_t *t =
+        tiles + (((long)f * tiles_y + (y >> 2)) * tiles_x + wx) * 4;
+    const int r = y & 3, sh = 16 * (r & 1);
+    const unsigned even = (t[r >> 1] >> sh) & 0xFFFFu;
+    const unsigned odd = (t[2 + (r >> 1)] >> sh) & 0xFFFFu;
+    bits[((long)f * (H + 2) + y + 1) * words_per_row + 1 + wx] =
+        spread16(even) | (spread16(odd) << 1);
+}
+
+__global__ __launch_bounds__(256) void blob_scan_bits_k(
+    const uint32_t *__restrict__ bits, int words_per_row, int W, int H,
+    int nframes, int words, Cand *__restrict__ cands,
+    unsigned *__restrict__ ctr, int band_rows, int nbands, unsigned band_cap) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)nframes * H * words;
+    if (tid >= total) return;
+    const int wx = (int)(tid % words);
+    const long fy = tid / words;
+    const int y = (int)(fy % H);
+    const int f = (int)(fy / H);
+    // guard row above row 0 and guard words left and right are zero
+    const uint32_t *row =
+        bits + ((long)f * (H + 2) + y + 1) * words_per_row + 1 + wx;
+    const uint32_t *up = row - words_per_row;
+    const unsigned cur = row[0], n = up[0];
+    const unsigned w = (cur << 1) | (row[-1] >> 31);
+    const unsigned nw = (n << 1) | (up[-1] >> 31);
+    const unsigned ne = (n >> 1) | (up[1] << 31);
+    const int left = W - wx * 32;
+    const unsigned valid = left >= 32 ? 0xFFFFFFFFu : (1u << left) - 1u;
+    unsigned outer = cur & ~w & ~n & ~nw & ~ne & valid;
+    unsigned hole = ~cur & w & n & valid;
+    const unsigned c = __popc(outer) + __popc(hole);
+    if (c == 0) return;
+    const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
+    unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
+    if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
+    Cand *list = cands + (size_t)bucket * band_cap;
+    const int x0 = wx * 32;
+    while (outer) {
+        const int i = __ffs(outer) - 1;
+        outer &= outer - 1;
+        if (at < band_cap)
+            list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i),
+                            (unsigned)f << 1};
+        ++at;
+    }
+    while (hole) {
+        const int i = __ffs(hole) - 1;
+        hole &= hole - 1;
+        if (at < band_cap)      // origin = the foreground pixel left of it
+            list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
+                            ((unsigned)f << 1) | 1u};
+        ++at;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3
 // ---------------------------------------------------------------------------
 // The same picture as 1 bit per pixel (written by blob_scan_k); `rows` is
@@ -567,8 +649,9 @@ struct hk_blob {
     unsigned band_cap = BAND_CAP0;      // entries per (frame, band) in cands
     // the batch in flight (collect() runs it again with larger buffers if
     // a list overflowed)
-    const uint8_t *masks = nullptr;
+    const uint8_t *masks = nullptr;     // null: the batch is in `tiles`
     long frame_stride = 0, pitch = 0;
+    uint32_t *tiles = nullptr;          // [max_frames][W/32 * H/4][4], lazily
     std::vector<unsigned> h_counts;     // per-band candidate counts
     // contours of a finished batch whose results did not fit the caller's
     // buffer: handed out by the next hk_blob_finish*() call
@@ -604,6 +687,7 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->recs);
     (void)hipFree(b->pts);
     (void)hipFree(b->bits);
+    (void)hipFree(b->tiles);
     (void)hipHostFree(b->h_ctr);
     (void)hipHostFree(b->h_recs);
     if (b->done) (void)hipEventDestroy(b->done);
@@ -728,16 +812,32 @@ static int launch_batch(hk_blob *b, int nframes) {
     const unsigned nbuckets = (unsigned)nframes * b->nbands;
     HK_HIP(hipMemsetAsync(b->ctr, 0,
                           sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
-    const int segs = (b->width + 15) / 16;
-    const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
-                     (nframes == 1 || frame_stride % 16 == 0);
-    const long total = (long)nframes * b->height * segs;
-    hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
-                       dim3(256), 0, s, masks, frame_stride, pitch, b->width,
-                       b->height, nframes, segs, vec, b->cands, b->ctr,
-                       b->band_rows, b->nbands, (unsigned short *)b->bits,
-                       b->words_per_row, b->band_cap);
-    HK_LAUNCH_CHECK("blob_scan_k");
+    if (!masks) {               // the MOG kernel's 1-bit tiles
+        const int tiles_x = b->width / 32, tiles_y = b->height / 4;
+        const long total = (long)nframes * b->height * tiles_x;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(blob_untile_k, dim3(blocks), dim3(256), 0, s,
+                           b->tiles, tiles_x, tiles_y, nframes, b->height,
+                           b->bits, b->words_per_row);
+        HK_LAUNCH_CHECK("blob_untile_k");
+        hipLaunchKernelGGL(blob_scan_bits_k, dim3(blocks), dim3(256), 0, s,
+                           b->bits, b->words_per_row, b->width, b->height,
+                           nframes, tiles_x, b->cands, b->ctr, b->band_rows,
+                           b->nbands, b->band_cap);
+        HK_LAUNCH_CHECK("blob_scan_bits_k");
+    } else {
+        const int segs = (b->width + 15) / 16;
+        const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&
+                         (nframes == 1 || frame_stride % 16 == 0);
+        const long total = (long)nframes * b->height * segs;
+        hipLaunchKernelGGL(blob_scan_k, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, s, masks, frame_stride, pitch,
+                           b->width, b->height, nframes, segs, vec, b->cands,
+                           b->ctr, b->band_rows, b->nbands,
+                           (unsigned short *)b->bits, b->words_per_row,
+                           b->band_cap);
+        HK_LAUNCH_CHECK("blob_scan_k");
+    }
     hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(256), b->trace_lds,
                        s, b->bits, b->words_per_row, b->width, b->height,
                        b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
@@ -776,6 +876,50 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
     b->masks = (const uint8_t *)mask_dev;
     b->frame_stride = frame_stride;
     b->pitch = pitch;
+    const int rc = launch_batch(b, nframes);
+    if (rc != HK_OK) return rc;
+    b->pending_frames = nframes;
+    return HK_OK;
+}
+
+extern "C" int hk_blob_tiles_buffer(hk_blob *b, void **tiles_dev,
+                                    long *words_per_frame) {
+    if (!b || !tiles_dev || !words_per_frame)
+        return hk::fail(HK_ERR_ARG, "hk_blob_tiles_buffer: null argument");
+    if (b->width % 32 || b->height % 4)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_tiles_buffer: %dx%d frames are not made of "
+                        "32x4 tiles", b->width, b->height);
+    const long wpf = (long)(b->width / 32) * (b->height / 4) * 4;
+    if (!b->tiles) {
+        hk::DeviceGuard guard(b->device);
+        HK_HIP(hipMalloc((void **)&b->tiles,
+                         sizeof(uint32_t) * wpf * b->max_frames));
+    }
+    *tiles_dev = b->tiles;
+    *words_per_frame = wpf;
+    return HK_OK;
+}
+
+extern "C" int hk_blob_enqueue_tiles(hk_blob *b, int nframes, void *stream) {
+    if (!b) return hk::fail(HK_ERR_ARG, "hk_blob_enqueue_tiles: null handle");
+    if (!b->tiles)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_enqueue_tiles: no tile buffer "
+                        "(hk_blob_tiles_buffer)");
+    if (nframes <= 0 || nframes > b->max_frames)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_enqueue_tiles: nframes %d outside 1..%d",
+                        nframes, b->max_frames);
+    if (b->pending_frames)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_blob_enqueue_tiles: previous batch not finished");
+    hk::DeviceGuard guard(b->device);
+    b->has_held = false;
+    b->held.clear();
+    b->stream = (hipStream_t)stream;
+    b->masks = nullptr;
+    b->frame_stride = b->pitch = 0;
     const int rc = launch_batch(b, nframes);
     if (rc != HK_OK) return rc;
     b->pending_frames = nframes;

@@ -384,7 +384,8 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     long bgr_frame_stride, uint8_t *__restrict__ mask, long mask_frame_stride,
     int nframes, int frames_before, const float *__restrict__ alpha_table,
     const MogConst c, int n_groups, const int *__restrict__ order,
-    int *__restrict__ cost) {
+    int *__restrict__ cost, unsigned *__restrict__ tiles,
+    long tile_words_per_frame) {
     // One wave per workgroup, so that a finished wave's slot and LDS are
     // reused at once (waves of one workgroup end at very different times).
     // A "group" is 4 units of 128 pixels that share cache lines of the frame
@@ -411,6 +412,10 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
         const int tx = (int)(tile - ty * tiles_x);
         i0 = (ty * 4 + (lane >> 4)) * width + tx * 32 + (lane & 15) * 2;
     }
+    // TILED only: where this wave's tile goes in the 1-bit output (4 words
+    // per tile and frame, see hk_mog_apply_batch_tiles), lanes 0-3 a word each
+    unsigned *tile_dst = nullptr;
+    if (TILED && tiles) tile_dst = tiles + (g >> 6) * 4 + (threadIdx.x & 3);
 
     // A component that was never created has weight 0 and all-zero fields
     // (the model starts zeroed, components are created with weight w0 > 0 and
@@ -507,8 +512,22 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                     m |= mog_step(l1, x0.y, x1.y, x2.y, alpha, c) << 8;
                     __builtin_amdgcn_s_setprio(0);
                 }
-                *reinterpret_cast<unsigned short *>(
-                    dst + (long)t * mask_frame_stride) = (unsigned short)m;
+                if (mask)
+                    *reinterpret_cast<unsigned short *>(
+                        dst + (long)t * mask_frame_stride) = (unsigned short)m;
+                if (TILED && tiles) {
+                    // foreground bits of the even and of the odd pixels of
+                    // the tile, a lane (= pixel pair) per bit
+                    const unsigned long long b0 =
+                        __builtin_amdgcn_ballot_w64((m & 1u) != 0u);
+                    const unsigned long long b1 =
+                        __builtin_amdgcn_ballot_w64((m & 0x100u) != 0u);
+                    if (threadIdx.x < 4) {
+                        const unsigned long long b = threadIdx.x & 2 ? b1 : b0;
+                        tile_dst[(long)t * tile_words_per_frame] =
+                            threadIdx.x & 1 ? (unsigned)(b >> 32) : (unsigned)b;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -773,12 +792,18 @@ extern "C" int hk_mog_reset(hk_mog *m, void *stream) {
 
 extern "C" int hk_mog_nframes(const hk_mog *m) { return m ? m->nframes : 0; }
 
-extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
-                                  long bgr_frame_stride, long bgr_pitch,
-                                  void *mask_dev, long mask_frame_stride,
-                                  long mask_pitch, int nframes, void *stream) {
-    if (!m || !bgr_dev || !mask_dev)
+// mask_dev and tiles_dev: either may be null, not both (tiles only with the
+// tiled kernel).
+static int apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
+                       long bgr_pitch, void *mask_dev, long mask_frame_stride,
+                       long mask_pitch, void *tiles_dev, int nframes,
+                       void *stream) {
+    if (!m || !bgr_dev || (!mask_dev && !tiles_dev))
         return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: null argument");
+    if (!mask_dev) {            // tiles only: no mask geometry to check
+        mask_pitch = m->width;
+        mask_frame_stride = (long)m->width * m->height;
+    }
     if (nframes < 0)
         return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: nframes %d", nframes);
     if (nframes == 0) return HK_OK;
@@ -810,8 +835,14 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
                            (const uint8_t *)bgr_dev,                          \
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
                            mask_frame_stride, nframes, m->nframes,            \
-                           m->alpha_table, m->c, m->n_groups, order, cost)
+                           m->alpha_table, m->c, m->n_groups, order, cost,    \
+                           (unsigned *)tiles_dev, tile_words)
         const bool tileable = m->width % 32 == 0 && m->height % 4 == 0;
+        const long tile_words = (N / 128) * 4;
+        if (tiles_dev && !tileable)
+            return hk::fail(HK_ERR_ARG,
+                            "hk_mog_apply_batch_tiles: %dx%d frames are not "
+                            "made of 32x4 tiles", m->width, m->height);
         // batches are launched slowest groups first (cost of the previous
         // batch); single frames are not worth the bookkeeping
         const int *order = nullptr;
@@ -837,6 +868,10 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
 #undef HK_MOG_LAUNCH
         HK_LAUNCH_CHECK("mog_batch2_k");
     } else {
+        if (tiles_dev)
+            return hk::fail(HK_ERR_ARG,
+                            "hk_mog_apply_batch_tiles: needs densely packed, "
+                            "2-byte aligned frames");
         const unsigned blocks = (unsigned)((N + 255) / 256);
         hipLaunchKernelGGL(mog_batch1_k, dim3(blocks), dim3(256), 0, s,
                            m->planes, N, m->width, (const uint8_t *)bgr_dev,
@@ -847,6 +882,34 @@ extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
     }
     m->nframes += nframes;
     return HK_OK;
+}
+
+extern "C" int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev,
+                                  long bgr_frame_stride, long bgr_pitch,
+                                  void *mask_dev, long mask_frame_stride,
+                                  long mask_pitch, int nframes, void *stream) {
+    if (!mask_dev)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: null argument");
+    return apply_batch(m, bgr_dev, bgr_frame_stride, bgr_pitch, mask_dev,
+                       mask_frame_stride, mask_pitch, nullptr, nframes, stream);
+}
+
+extern "C" int hk_mog_tiles_supported(const hk_mog *m) {
+    return m && m->width % 32 == 0 && m->height % 4 == 0 ? 1 : 0;
+}
+
+extern "C" int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
+                                        long bgr_frame_stride, long bgr_pitch,
+                                        void *tiles_dev, int nframes,
+                                        void *stream) {
+    if (!tiles_dev)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch_tiles: null argument");
+    if (m && ((uintptr_t)tiles_dev & 15))
+        return hk::fail(HK_ERR_ARG,
+                        "hk_mog_apply_batch_tiles: tiles must be 16-byte "
+                        "aligned");
+    return apply_batch(m, bgr_dev, bgr_frame_stride, bgr_pitch, nullptr, 0, 0,
+                       tiles_dev, nframes, stream);
 }
 
 extern "C" int hk_mog_apply(hk_mog *m, const void *bgr_dev, long bgr_pitch,

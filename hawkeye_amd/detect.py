@@ -8,6 +8,8 @@ Host-side mirror of the two OpenCV objects the reference's step 2 uses
 Frames and masks are PyTorch-ROCm uint8 tensors (plumbing only: device memory
 and the current HIP stream); all arithmetic happens in libhawkeye_hip.so.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -87,6 +89,25 @@ class BackgroundSubtractorMOG:
             _stream_ptr(self.device)))
         return out
 
+    @property
+    def tiles_supported(self):
+        """The 1-bit tile output needs frames made of 32x4 pixel tiles."""
+        return bool(nat.lib.hk_mog_tiles_supported(self._h))
+
+    def apply_batch_tiles(self, frames, tiles_ptr):
+        """apply_batch() with the masks written as 1-bit tiles into the
+        device buffer at `tiles_ptr` (SimpleBlobDetector.tiles_buffer)."""
+        frames = self._as_device_frames(frames)
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (
+                self.height, self.width, 3):
+            raise ValueError('frames shape {} != (T, {}, {}, 3)'.format(
+                tuple(frames.shape), self.height, self.width))
+        if not frames.is_contiguous():
+            frames = frames.contiguous()
+        nat.check(nat.lib.hk_mog_apply_batch_tiles(
+            self._h, frames.data_ptr(), frames.stride(0), frames.stride(1),
+            tiles_ptr, frames.shape[0], _stream_ptr(self.device)))
+
     def export_model(self):
         """Mixture model as float32 [H*W][5][8] in OpenCV's MixData order
         (sortKey, weight, mean[3], var[3]); for parity tests."""
@@ -161,6 +182,21 @@ class SimpleBlobDetector:
         self._pending = masks.shape[0]
         self._keep = masks
 
+    def tiles_buffer(self):
+        """Device address of the handle's 1-bit tile buffer (room for
+        max_frames frames), which BackgroundSubtractorMOG.apply_batch_tiles
+        fills; enqueue_tiles() then detects on it."""
+        ptr, words = nat.C.c_void_p(), nat.C.c_long()
+        nat.check(nat.lib.hk_blob_tiles_buffer(self._h, nat.C.byref(ptr),
+                                               nat.C.byref(words)))
+        return ptr.value
+
+    def enqueue_tiles(self, nframes, stream=None):
+        sp = _stream_ptr(self.device) if stream is None else stream.cuda_stream
+        nat.check(nat.lib.hk_blob_enqueue_tiles(self._h, int(nframes), sp))
+        self._pending = int(nframes)
+        self._keep = None
+
     def _split(self, flat, total):
         out, k = [], 0
         for t in range(self._pending):
@@ -231,9 +267,18 @@ class EventDetector:
         self.blob = [SimpleBlobDetector(width, height, blob_params,
                                         max_frames=self.chunk, device=device)
                      for _ in range(self.DEPTH)]
-        self.masks = [torch.empty((self.chunk, self.height, self.width),
-                                  dtype=torch.uint8, device=self.device)
-                      for _ in range(self.DEPTH)]
+        # The MOG kernel hands the masks over as 1-bit tiles where the frame
+        # geometry allows (1/8 of the bytes for the blob scan, none written
+        # as bytes); otherwise as byte images.  Same events either way.
+        self.use_tiles = self.mog.tiles_supported and \
+            os.environ.get('HK_DETECT_TILES', '1') != '0'
+        if self.use_tiles:
+            self._tiles = [b.tiles_buffer() for b in self.blob]
+            self.masks = None
+        else:
+            self.masks = [torch.empty((self.chunk, self.height, self.width),
+                                      dtype=torch.uint8, device=self.device)
+                          for _ in range(self.DEPTH)]
         self._next = 0              # chunks submitted so far
         self._collected = 0         # chunks whose keypoints were returned
         # set to a list to collect (start, end, frames) event triples of the
@@ -253,20 +298,30 @@ class EventDetector:
         if self._next - self._collected >= self.DEPTH:      # set still busy
             out = self._collect()
         p = self._next % self.DEPTH
-        masks = self.masks[p][:t]
         main = torch.cuda.current_stream(self.device)
+        if self.use_tiles:
+            def run_mog():
+                self.mog.apply_batch_tiles(frames, self._tiles[p])
+        else:
+            masks = self.masks[p][:t]
+
+            def run_mog():
+                self.mog.apply_batch(frames, out=masks)
         if self.mog_timing is None:
-            self.mog.apply_batch(frames, out=masks)
+            run_mog()
         else:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(main)
-            self.mog.apply_batch(frames, out=masks)
+            run_mog()
             e1.record(main)
             self.mog_timing.append((e0, e1, t))
         self._mog_done[p].record(main)
         self._side.wait_event(self._mog_done[p])
-        self.blob[p].enqueue(masks, stream=self._side)
+        if self.use_tiles:
+            self.blob[p].enqueue_tiles(t, stream=self._side)
+        else:
+            self.blob[p].enqueue(masks, stream=self._side)
         self._next += 1
         # keep DEPTH - 1 chunks in flight behind the one just launched
         while self._next - self._collected > self.DEPTH - 1:

@@ -83,6 +83,21 @@ int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
                        long bgr_pitch, void *mask_dev, long mask_frame_stride,
                        long mask_pitch, int nframes, void *stream);
 
+/* The same launch with the foreground mask written as 1 bit per pixel for the
+ * blob detector (hk_blob_tiles_buffer / hk_blob_enqueue_tiles) instead of a
+ * byte image: per frame and 32x4 pixel tile (tiles in raster order) four
+ * 32-bit words, the bits of the tile's even pixels (16 per row, rows 0-3) and
+ * then of its odd pixels.  Same model update, same mask bits as
+ * hk_mog_apply_batch.  Needs width % 32 == 0, height % 4 == 0
+ * (hk_mog_tiles_supported) and densely packed frames (bgr_pitch == 3*width);
+ * tiles_dev 16-byte aligned, frame t at tiles_dev + t * (W/32)*(H/4)*4 words.
+ * No counterpart in the reference (its fgmask is a byte image,
+ * tracker.py:395). */
+int hk_mog_tiles_supported(const hk_mog *m);
+int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
+                             long bgr_frame_stride, long bgr_pitch,
+                             void *tiles_dev, int nframes, void *stream);
+
 /* Copies the model to host in OpenCV's AoS order: float [H*W][5][8] =
  * (sortKey, weight, mean[3], var[3]).  For tests.  Synchronises. */
 int hk_mog_export_model(hk_mog *m, float *host_out, void *stream);
@@ -142,6 +157,14 @@ int hk_blob_destroy(hk_blob *b);
  * lists, as OpenCV has no limit on the number of contours. */
 int hk_blob_enqueue(hk_blob *b, const void *mask_dev, long frame_stride,
                     long pitch, int nframes, void *stream);
+/* The same, fed by the MOG kernel's 1-bit output instead of byte masks (1/8 of
+ * the bytes; no counterpart in the reference, whose fgmask is a byte image:
+ * tracker.py:395-396).  hk_blob_tiles_buffer() returns the handle's device
+ * buffer, which hk_mog_apply_batch_tiles() fills for up to max_frames frames;
+ * hk_blob_enqueue_tiles() then runs detection on its first nframes frames.
+ * Frames must be made of 32x4 tiles (width % 32 == 0, height % 4 == 0). */
+int hk_blob_tiles_buffer(hk_blob *b, void **tiles_dev, long *words_per_frame);
+int hk_blob_enqueue_tiles(hk_blob *b, int nframes, void *stream);
 /* Wait for the enqueued batch and finish on the host (ordering, radius,
  * grouping).  counts_host[t] = keypoints of frame t; kp_host receives
  * (x, y, size) float triples, frame after frame; *total = sum of counts.

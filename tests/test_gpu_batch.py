@@ -139,3 +139,36 @@ def test_pinned_host_source_streams_the_same_frames():
         assert len(got) == len(want) == len(got2) == spec['frames']
         for a, b, c in zip(want, got, got2):
             assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_tile_path_equals_byte_path(monkeypatch):
+    from hawkeye_amd import synth
+    """Step 2 with the MOG kernel's masks handed to the blob detector as
+    1-bit tiles (the default where frames are made of 32x4 tiles) and as byte
+    images gives the same keypoints, bit for bit; so does a chunk length that
+    leaves a ragged last chunk."""
+    from hawkeye_amd.detect import EventDetector, hawkeye_blob_params
+    spec = dict(width=640, height=360, fps=60.0, balls=7, frames=150,
+                ball_r=6.0, sigma=3.0, drift=6.0, drift_hz=0.3,
+                distractors=12, seed=4242)
+    frames = synth.ClipRenderer(spec).render(0, spec['frames'])
+
+    def run(tiles, chunk):
+        monkeypatch.setenv('HK_DETECT_TILES', '1' if tiles else '0')
+        det = EventDetector(spec['width'], spec['height'],
+                            hawkeye_blob_params(spec['height']), chunk=chunk)
+        assert det.use_tiles == tiles
+        out = []
+        for s in range(0, spec['frames'], chunk):
+            out += det.submit(frames[s:s + chunk])
+        out += det.flush()
+        det.close()
+        return out
+
+    want = run(False, 64)
+    assert sum(len(k) for k in want) > 500
+    for chunk in (64, 37, 1):
+        got = run(True, chunk)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
