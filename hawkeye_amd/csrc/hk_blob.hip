@@ -186,10 +186,13 @@ __global__ __launch_bounds__(256) void blob_scan_k(
 
 // ---------------------------------------------------------------------------
 // K2 fed by the MOG kernel's 1-bit tiles (hk_mog_apply_batch_tiles): per
-// 32 x 4 pixel tile and frame four words, the foreground bits of the tile's
-// even pixels (lane order: 16 per row) and of its odd pixels.  blob_untile_k
-// interleaves them into the padded 1-bit image, blob_scan_bits_k finds the
-// candidate border starts on whole words -- 1/8 of the bytes blob_scan_k reads.
+// 32 x 4 pixel tile and frame four words -- the foreground bits of the tile's
+// even pixels (16 per row: rows 0-1, rows 2-3) and of its odd pixels.  One
+// lane per tile interleaves them into four words of the padded 1-bit image
+// and finds the candidate border starts of its 128 pixels on whole words; the
+// neighbour bits it needs from the tiles around come straight out of their
+// planes (bit 31 of a word = bit 15 of the odd plane, bit 0 = bit 0 of the
+// even plane).  1/8 of the bytes blob_scan_k reads, and no byte masks at all.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned spread16(unsigned v) {  // bit i -> bit 2i
     v = (v | (v << 8)) & 0x00FF00FFu;
@@ -199,55 +202,20 @@ __device__ __forceinline__ unsigned spread16(unsigned v) {  // bit i -> bit 2i
     return v;
 }
 
-__global__ __launch_bounds__(256) void blob_untile_k(
-    const uint32_t *__restrict__ tiles, int tiles_x, int tiles_y, int nframes,
-    int H, uint32_t *__restrict__ bits, int words_per_row) {
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)nframes * H * tiles_x;
-    if (tid >= total) return;
-    const int wx = (int)(tid % tiles_x);
-    const long fy = tid / tiles_x;
-    const int y = (int)(fy % H);
-    const int f = (int)(fy / H);
-    const uint32_t *t =
-        tiles + (((long)f * tiles_y + (y >> 2)) * tiles_x + wx) * 4;
-    const int r = y & 3, sh = 16 * (r & 1);
-    const unsigned even = (t[r >> 1] >> sh) & 0xFFFFu;
-    const unsigned odd = (t[2 + (r >> 1)] >> sh) & 0xFFFFu;
-    bits[((long)f * (H + 2) + y + 1) * words_per_row + 1 + wx] =
-        spread16(even) | (spread16(odd) << 1);
+__device__ __forceinline__ unsigned plane_row(unsigned p01, unsigned p23,
+                                              int r) {
+    return ((r & 2 ? p23 : p01) >> (16 * (r & 1))) & 0xFFFFu;
 }
 
-__global__ __launch_bounds__(256) void blob_scan_bits_k(
-    const uint32_t *__restrict__ bits, int words_per_row, int W, int H,
-    int nframes, int words, Cand *__restrict__ cands,
-    unsigned *__restrict__ ctr, int band_rows, int nbands, unsigned band_cap) {
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)nframes * H * words;
-    if (tid >= total) return;
-    const int wx = (int)(tid % words);
-    const long fy = tid / words;
-    const int y = (int)(fy % H);
-    const int f = (int)(fy / H);
-    // guard row above row 0 and guard words left and right are zero
-    const uint32_t *row =
-        bits + ((long)f * (H + 2) + y + 1) * words_per_row + 1 + wx;
-    const uint32_t *up = row - words_per_row;
-    const unsigned cur = row[0], n = up[0];
-    const unsigned w = (cur << 1) | (row[-1] >> 31);
-    const unsigned nw = (n << 1) | (up[-1] >> 31);
-    const unsigned ne = (n >> 1) | (up[1] << 31);
-    const int left = W - wx * 32;
-    const unsigned valid = left >= 32 ? 0xFFFFFFFFu : (1u << left) - 1u;
-    unsigned outer = cur & ~w & ~n & ~nw & ~ne & valid;
-    unsigned hole = ~cur & w & n & valid;
+__device__ __forceinline__ void emit_candidates(
+    unsigned outer, unsigned hole, int f, int y, int x0, Cand *cands,
+    unsigned *ctr, int band_rows, int nbands, unsigned band_cap) {
     const unsigned c = __popc(outer) + __popc(hole);
     if (c == 0) return;
     const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
     if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
     Cand *list = cands + (size_t)bucket * band_cap;
-    const int x0 = wx * 32;
     while (outer) {
         const int i = __ffs(outer) - 1;
         outer &= outer - 1;
@@ -263,6 +231,57 @@ __global__ __launch_bounds__(256) void blob_scan_bits_k(
             list[at] = Cand{((unsigned)y << 16) | (unsigned)(x0 + i - 1),
                             ((unsigned)f << 1) | 1u};
         ++at;
+    }
+}
+
+__global__ __launch_bounds__(256) void blob_scan_tiles_k(
+    const uint4 *__restrict__ tiles, int tiles_x, int tiles_y, int nframes,
+    int H, uint32_t *__restrict__ bits, int words_per_row,
+    Cand *__restrict__ cands, unsigned *__restrict__ ctr, int band_rows,
+    int nbands, unsigned band_cap) {
+    const long per_frame = (long)tiles_x * tiles_y;
+    const long total = (long)nframes * per_frame;
+    for (long tid = (long)blockIdx.x * 256 + threadIdx.x; tid < total;
+         tid += (long)gridDim.x * 256) {
+        const int f = (int)(tid / per_frame);
+        const int rest = (int)(tid - (long)f * per_frame);
+        const int ty = rest / tiles_x, tx = rest - ty * tiles_x;
+        const uint4 *frame = tiles + (long)f * per_frame;
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        // x = even rows 0-1, y = even rows 2-3, z = odd rows 0-1, w = odd 2-3
+        const uint4 me = frame[rest];
+        const uint4 lt = tx > 0 ? frame[rest - 1] : zero;
+        const uint4 rt = tx + 1 < tiles_x ? frame[rest + 1] : zero;
+        uint4 up = zero, ul = zero, ur = zero;
+        if (ty > 0) {
+            up = frame[rest - tiles_x];
+            if (tx > 0) ul = frame[rest - tiles_x - 1];
+            if (tx + 1 < tiles_x) ur = frame[rest - tiles_x + 1];
+        }
+        // the row above the tile: its word, and the bits beside it
+        unsigned n = spread16(up.y >> 16) | (spread16(up.w >> 16) << 1);
+        unsigned n_left31 = ul.w >> 31;
+        unsigned n_right0 = (ur.y >> 16) & 1u;
+        uint32_t *dst = bits + ((long)f * (H + 2) + ty * 4 + 1) *
+                                   words_per_row + 1 + tx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned cur = spread16(plane_row(me.x, me.y, r)) |
+                                 (spread16(plane_row(me.z, me.w, r)) << 1);
+            const unsigned left31 = plane_row(lt.z, lt.w, r) >> 15;
+            const unsigned right0 = plane_row(rt.x, rt.y, r) & 1u;
+            dst[(long)r * words_per_row] = cur;
+            const unsigned w = (cur << 1) | left31;
+            const unsigned nw = (n << 1) | n_left31;
+            const unsigned ne = (n >> 1) | (n_right0 << 31);
+            const unsigned outer = cur & ~w & ~n & ~nw & ~ne;
+            const unsigned hole = ~cur & w & n;
+            emit_candidates(outer, hole, f, ty * 4 + r, tx * 32, cands, ctr,
+                            band_rows, nbands, band_cap);
+            n = cur;
+            n_left31 = left31;
+            n_right0 = right0;
+        }
     }
 }
 
@@ -814,17 +833,16 @@ static int launch_batch(hk_blob *b, int nframes) {
                           sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
     if (!masks) {               // the MOG kernel's 1-bit tiles
         const int tiles_x = b->width / 32, tiles_y = b->height / 4;
-        const long total = (long)nframes * b->height * tiles_x;
-        const unsigned blocks = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(blob_untile_k, dim3(blocks), dim3(256), 0, s,
-                           b->tiles, tiles_x, tiles_y, nframes, b->height,
-                           b->bits, b->words_per_row);
-        HK_LAUNCH_CHECK("blob_untile_k");
-        hipLaunchKernelGGL(blob_scan_bits_k, dim3(blocks), dim3(256), 0, s,
-                           b->bits, b->words_per_row, b->width, b->height,
-                           nframes, tiles_x, b->cands, b->ctr, b->band_rows,
-                           b->nbands, b->band_cap);
-        HK_LAUNCH_CHECK("blob_scan_bits_k");
+        const long total = (long)nframes * tiles_x * tiles_y;
+        // few, long-lived workgroups: this runs beside the MOG launch of the
+        // next chunk, which leaves wave slots free only now and then
+        const unsigned blocks =
+            (unsigned)std::min<long>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(blob_scan_tiles_k, dim3(blocks), dim3(256), 0, s,
+                           (const uint4 *)b->tiles, tiles_x, tiles_y, nframes,
+                           b->height, b->bits, b->words_per_row, b->cands,
+                           b->ctr, b->band_rows, b->nbands, b->band_cap);
+        HK_LAUNCH_CHECK("blob_scan_tiles_k");
     } else {
         const int segs = (b->width + 15) / 16;
         const bool vec = ((uintptr_t)masks % 16 == 0) && pitch % 16 == 0 &&

@@ -14,25 +14,29 @@ for rep in range(3):
     t_sub = t_col = 0.0
     t0 = time.perf_counter()
     col_orig = det._collect
-    def timed_collect(p):
+    def timed_collect(*p):
         global t_col
-        a = time.perf_counter(); r = col_orig(p); t_col += time.perf_counter() - a
+        a = time.perf_counter(); r = col_orig(*p); t_col += time.perf_counter() - a
         return r
     det._collect = timed_collect
     n = 0
+    per_chunk = []
     for s in range(0, frames.shape[0], 128):
         a = time.perf_counter()
         out = det.submit(frames[s:s + 128])
         t_sub += time.perf_counter() - a
+        per_chunk.append(time.perf_counter() - a)
         n += len(out)
     n += len(det.flush())
     det._collect = col_orig
     total = time.perf_counter() - t0
+    per = sorted(per_chunk)
+    print('per-chunk submit ms:', ' '.join('%.2f' % (v * 1e3) for v in per_chunk))
     print('total %.1f ms, submit (incl. collect) %.1f ms, collect %.1f ms, frames %d'
           % (total * 1e3, t_sub * 1e3, t_col * 1e3, n))
 # GPU-only: all kernels without collecting in between
 torch.cuda.synchronize()
-masks = det.masks[0]
+masks = torch.empty((128, spec['height'], spec['width']), dtype=torch.uint8, device='cuda')
 det.mog.reset()
 det.mog.apply_batch(frames[256:384], out=masks)
 for rep in range(3):
