@@ -54,6 +54,7 @@ _sig('hk_version', [])
 _sig('hk_device_count', [])
 _sig('hk_release_cached_memory', [])
 _sig('hk_set_host_threads', [C.c_int])
+_sig('hk_step3_help', [C.c_int])
 _sig('hk_set_self_check', [C.c_int])
 
 _sig('hk_mog_create', [C.c_int, C.c_int, C.c_int, c_void_pp])

@@ -209,25 +209,15 @@ class ClipScanner:
 
         A step-3 build runs seeds speculatively ahead of its committer, and
         speculation re-does work: measured on MI355X + 16 cores (1080p60
-        9-ball clip, tools/sweep_builders.sh) one clip costs 178 ms of one
-        core, 2 x 112, 3 x 85 or 7 x 43 ms.  Many clips on one thread each
-        give the highest rate (13 ms per clip, what the GPU detects at) but
-        the last clips of the batch leave after a whole single-thread build;
-        few clips on many threads each start and drain fast and top out at
-        22 ms per clip.  The break-even batch sizes below are the measured
-        ones (80 clips: 115k frames/s against 77k; 20 clips: 87k against 80k).
-        """
+        9-ball clip, tools/sweep_builders.sh) one clip costs 147 ms of one
+        core, but 183 / 227 / 260 ms of core time on 2 / 7 / 16 threads.  So
+        every clip is built on one thread of its own, as many clips at a time
+        as there are cores (or clips), and threads that have no clip -- while
+        the batch fills up, and when it drains -- help the builds in progress
+        (hk_step3_help) instead of owning a share of a build."""
         if cores is None:
             cores = host_core_share()
-        spare = max(1, cores - 2)
-        if count is None or count >= 40:
-            threads = 1
-        elif count >= 12:
-            threads = 2
-        else:
-            threads = max(1, spare // 2)
-        threads = min(threads, spare)
-        return max(1, spare // threads), threads
+        return max(1, cores - 2), 1
 
     def scan_many(self, clips, host_threads=None, builders=None, count=None):
         """Generator over the results of `clips` (an iterable of frame
@@ -287,22 +277,61 @@ class ClipScanner:
                 for _ in range(builders):
                     put(detected, END)
 
+        # A builder thread with no clip of its own helps the step-3 builds
+        # the other threads are running (hk_step3_help: it runs seeds ahead
+        # of that build's committer; results do not depend on it), so the
+        # host cores stay busy while the batch fills up and while it drains.
+        # Only while fewer than half of the builder threads have a clip:
+        # with most of them busy a helper adds more contention (and a clip
+        # that arrives meanwhile waits for it) than it saves.
+        HELP_SEEDS = 512
+        building = [0]
+        lock = threading.Lock()
+
+        def next_clip():
+            """The next detected clip; helps running builds while waiting."""
+            while not stop.is_set():
+                try:
+                    return detected.get_nowait()
+                except queue.Empty:
+                    pass
+                if 2 * building[0] >= builders or \
+                        not nat.lib.hk_step3_help(HELP_SEEDS):
+                    try:
+                        return detected.get(timeout=0.002)
+                    except queue.Empty:
+                        pass
+            return END
+
         def build_stage():
             try:
                 torch.cuda.set_device(self.device)
                 while True:
-                    item = get(detected)
+                    item = next_clip()
                     if item is END:
-                        return
+                        break
                     seq, per_frame, res = item
+                    with lock:
+                        building[0] += 1
                     try:
                         done = self.build_arcs(per_frame, res)
                     except BaseException as exc:    # noqa: B902
                         put(built, (seq, exc))
                         return
+                    finally:
+                        with lock:
+                            building[0] -= 1
                     if not put(built, (seq, done)):
                         done[1].close()
                         return
+                # every clip has been taken by some builder (END follows the
+                # last one): help those still building
+                while not stop.is_set():
+                    with lock:
+                        if building[0] == 0:
+                            break
+                    if not nat.lib.hk_step3_help(HELP_SEEDS):
+                        time.sleep(0.0005)
             finally:
                 put(built, END)
 

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "hk_clip.h"
@@ -234,6 +235,15 @@ static S3Prof g_s3prof;         // single-thread measurements only
 #define S3P_CNT(k, n) do {} while (0)
 #endif
 
+// Full passes in progress that threads from outside may join
+// (hk_step3_help): in a batch most clips are built on one thread each, and
+// when the batch runs out the threads that have no clip left help the builds
+// still going instead of idling.
+class ArcBuilder;
+std::mutex g_open_mu;
+std::vector<ArcBuilder *> g_open_builders;
+constexpr int MAX_SEED_THREADS = 16;    // own workers + helpers per build
+
 class ArcBuilder {
 public:
     explicit ArcBuilder(hk_clip &c)
@@ -285,8 +295,8 @@ public:
             for (int k = 0; k < c.n; ++k)
                 xs_val_[(size_t)k] = c.x[xs_idx_[(size_t)k]];
         }
-        nthreads_ = worker_count();
-        scratch_.reset(new Scratch[(size_t)nthreads_]);
+        nthreads_ = std::min(worker_count(), MAX_SEED_THREADS);
+        scratch_.reset(new Scratch[(size_t)MAX_SEED_THREADS]);
         for (int t = 0; t < nthreads_; ++t) scratch_[t].init(c.n, c.F);
         for (int t = 1; t < nthreads_; ++t)
             pool_.emplace_back([this, t] { worker_loop(scratch_[t]); });
@@ -319,7 +329,7 @@ public:
             done_[i].store(0, std::memory_order_relaxed);
             taken_[i].store(0, std::memory_order_relaxed);
         }
-        for (int t = 0; t < nthreads_; ++t) scratch_[t].pool_reset();
+        for (int t = 0; t < MAX_SEED_THREADS; ++t) scratch_[t].pool_reset();
 
         const bool use_device = maxcount <= 0 && has_vmax_ && x_index_ok_ &&
                                 device_wanted();
@@ -332,6 +342,9 @@ public:
         size_t want = maxcount > 0 ? (size_t)nthreads_
                                    : (size_t)std::max(8, per_thread * nthreads_);
         if (nthreads_ == 1) want = 1;
+        // helpers may join a full pass: leave them room to run ahead
+        const bool joinable = maxcount <= 0 && n_ >= 1024;
+        if (joinable) want = std::max(want, (size_t)(per_thread * 4));
         window_ = 1;
         while (window_ < want) window_ <<= 1;
         slots_.reset(new Slot[window_]);
@@ -366,6 +379,11 @@ public:
 
         active_.store(nthreads_ - 1);
         generation_.fetch_add(1);               // release the workers
+        if (joinable) {
+            std::lock_guard<std::mutex> lock(g_open_mu);
+            helper_slots_used_ = 0;
+            g_open_builders.push_back(this);
+        }
 
         Scratch &mine = scratch_[0];
         const size_t Q = (size_t)n_;
@@ -419,8 +437,23 @@ public:
                 (maxcount > 0 && (int)out.size() >= maxcount))
                 break;
         }
+        if (joinable) {     // no new helpers from here on
+            std::lock_guard<std::mutex> lock(g_open_mu);
+            g_open_builders.erase(std::find(g_open_builders.begin(),
+                                            g_open_builders.end(), this));
+        }
         stop_.store(true, std::memory_order_release);
-        while (active_.load(std::memory_order_acquire) > 0) cpu_relax();
+        {
+            int spins = 0;
+            while (active_.load(std::memory_order_acquire) > 0) {
+                if (++spins > 2000) {
+                    std::this_thread::yield();
+                    spins = 0;
+                } else {
+                    cpu_relax();
+                }
+            }
+        }
         if (feeder.joinable()) feeder.join();
         if (dev_) {
             seed_close(dev_);
@@ -430,11 +463,59 @@ public:
                           dev_message_);
         }
         stat_busy_ms_ = 0;
-        for (int t = 0; t < nthreads_; ++t) {
+        for (int t = 0; t < MAX_SEED_THREADS; ++t) {
             stat_busy_ms_ += scratch_[t].busy_ms;
             scratch_[t].busy_ms = 0;
         }
         return rc;
+    }
+
+    // Work left per thread on it: what a helper looks at to choose a build.
+    // Call with g_open_mu held.
+    double load_per_thread() const {
+        const size_t done = commit_pos_.load(std::memory_order_relaxed);
+        const int threads = nthreads_ + __builtin_popcount(helper_slots_used_);
+        return (double)((size_t)n_ - std::min(done, (size_t)n_)) / threads;
+    }
+
+    // Takes a free scratch slot for a helper; call with g_open_mu held (the
+    // builder is in g_open_builders, so its pass is running and it will wait
+    // for active_ to drop before it ends).  -1 if all slots are taken.
+    int helper_join() {
+        for (int t = nthreads_; t < MAX_SEED_THREADS; ++t)
+            if (!(helper_slots_used_ & (1u << t))) {
+                helper_slots_used_ |= 1u << t;
+                active_.fetch_add(1, std::memory_order_acq_rel);
+                return t;
+            }
+        return -1;
+    }
+
+    // The calling thread runs seeds of this pass until there is none left to
+    // claim or the pass ends.  After the final fetch_sub the builder may be
+    // gone: nothing of it is touched afterwards.
+    void helper_work(int slot, int max_seeds) {
+        Scratch &s = scratch_[slot];
+        if ((int)s.marks.size() != n_) s.init(c_.n, c_.F);
+        int idle = 0, ran = 0;
+        while (!stop_.load(std::memory_order_acquire) &&
+               next_.load(std::memory_order_relaxed) < (size_t)n_ &&
+               ran < max_seeds) {
+            if (run_next(s)) {
+                idle = 0;
+                ++ran;
+            } else if (++idle > 2000) {
+                std::this_thread::yield();
+                idle = 0;
+            } else {
+                cpu_relax();
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lock(g_open_mu);
+            helper_slots_used_ &= ~(1u << slot);
+        }
+        active_.fetch_sub(1, std::memory_order_release);
     }
 
     // Seeds on the GPU are opt-in (HK_STEP3_DEVICE=1; 2 = whatever the clip's
@@ -1206,6 +1287,7 @@ private:
     std::atomic<unsigned> generation_{0};
     std::atomic<bool> quit_{false}, stop_{false};
     int nthreads_ = 1;
+    unsigned helper_slots_used_ = 0;    // scratch slots of helpers (g_open_mu)
     // HK_STEP3_SIMD=0: the scalar loops (tests compare the two)
     const bool simd_ = simd_available() &&
                        !(getenv("HK_STEP3_SIMD") &&
@@ -1888,6 +1970,32 @@ extern "C" int hk_release_cached_memory(void) {
     hk::seed_release_cached();
     hk::em_release_cached();
     return HK_OK;
+}
+
+// The calling thread helps a step-3 build of this process that is in its full
+// pass (the one with the most seeds left per thread) for up to max_seeds
+// seeds, or until that build has no seed left to hand out.  Returns 1 if it
+// helped, 0 if there was nothing to help with.  Results do not depend on it
+// (speculative seeds, committed in order: see ArcBuilder).
+extern "C" int hk_step3_help(int max_seeds) {
+    if (max_seeds <= 0) return 0;
+    hk::ArcBuilder *b = nullptr;
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lock(hk::g_open_mu);
+        double best = 64.0;             // not worth joining for a few seeds
+        for (hk::ArcBuilder *cand : hk::g_open_builders) {
+            const double load = cand->load_per_thread();
+            if (load > best) {
+                best = load;
+                b = cand;
+            }
+        }
+        if (b) slot = b->helper_join();
+    }
+    if (!b || slot < 0) return 0;
+    b->helper_work(slot, max_seeds);
+    return 1;
 }
 
 extern "C" int hk_set_host_threads(int n) {

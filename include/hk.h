@@ -277,6 +277,13 @@ int hk_clip_get_tag_state(const hk_clip *c, unsigned char *alive,
 
 /* Step 3 (host only; multi-threaded, same result for any thread count). */
 int hk_clip_build_initial_arcs(hk_clip *c);
+/* Batches: the calling thread lends a hand to a step-3 build that another
+ * thread of this process is running (hk_clip_build_initial_arcs in its full
+ * pass), for up to max_seeds seeds.  Returns 1 if it helped, 0 if no build
+ * had work to share.  The build's result does not depend on it.  No
+ * counterpart in the reference (one thread, tracker.py:487-652). */
+int hk_step3_help(int max_seeds);
+
 /* Host threads step 3 may use: 0 = automatic (the smaller of the hardware
  * concurrency, OMP_NUM_THREADS and 16), else exactly n (at most 16). */
 int hk_set_host_threads(int n);

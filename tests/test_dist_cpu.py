@@ -110,8 +110,7 @@ def test_host_core_share_and_stage_plan(monkeypatch):
     plan = batch.ClipScanner.plan_host_stage
     assert plan(None, cores=16) == (14, 1)
     assert plan(80, cores=16) == (14, 1)
-    assert plan(20, cores=16) == (7, 2)
-    assert plan(4, cores=16) == (2, 7)
+    assert plan(4, cores=16) == (14, 1)
     for count in (None, 1, 20, 100):
         for cores in (1, 2, 3, 8, 16):
             b, t = plan(count, cores=cores)

@@ -138,3 +138,71 @@ def test_result_does_not_depend_on_thread_count_or_window(monkeypatch):
     monkeypatch.setenv('HK_STEP3_SIMD', '0')
     assert run(1, 16) == want
     assert run(4, 64) == want
+
+
+def test_helper_threads_do_not_change_the_result():
+    """Threads without a clip of their own help running builds
+    (hk_step3_help, what scan_many's idle builder threads do): three clips
+    built at the same time on one thread each, four helpers hopping between
+    them with small seed budgets; every result equals the unhelped one."""
+    import threading
+    from hawkeye_amd import _native as nat
+    inputs = []
+    for k in range(3):
+        scene = synth.JugglingScene(1280, 720, 60.0, 5 + k, 300, 950 + k)
+        meas = synth.make_tags(scene, 960 + k, clutter_per_frame=12.0)
+        rng = np.random.RandomState(970 + k)
+        for d in range(5):
+            px, py = rng.uniform(100, 1100), rng.uniform(100, 600)
+            for f in range(300):
+                px += rng.normal(0, 1.2)
+                py += rng.normal(0, 1.2)
+                meas.setdefault(f, []).append((px, py, 14.0 + d))
+        inputs.append(synth.tags_to_soa(meas, 300))
+
+    def build(soa):
+        frame, x, y, r, tw, start = soa
+        clip = Clip(1280, 720, 60.0, 300, frame, x, y, r, tw, stream=0)
+        clip.build_initial_arcs()
+        params, ids, tags = clip.arcs()
+        out = (params.tobytes(), ids.tobytes(),
+               tuple(t.tobytes() for t in tags))
+        clip.close()
+        return out
+
+    nat.check(nat.lib.hk_set_host_threads(1))
+    try:
+        want = [build(soa) for soa in inputs]
+        assert all(len(w[2]) > 10 for w in want)
+        for budget in (7, 2048):
+            got = [None] * len(inputs)
+            running = [len(inputs)]
+            helped = [0]
+            lock = threading.Lock()
+
+            def builder(k):
+                got[k] = build(inputs[k])
+                with lock:
+                    running[0] -= 1
+
+            def helper():
+                while True:
+                    with lock:
+                        if running[0] == 0:
+                            return
+                    if nat.lib.hk_step3_help(budget):
+                        with lock:
+                            helped[0] += 1
+
+            threads = [threading.Thread(target=builder, args=(k,))
+                       for k in range(len(inputs))] + \
+                      [threading.Thread(target=helper) for _ in range(4)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert got == want, budget
+            assert helped[0] > 0
+    finally:
+        nat.check(nat.lib.hk_set_host_threads(0))
+    assert nat.lib.hk_step3_help(100) == 0      # nothing to help with
