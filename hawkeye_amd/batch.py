@@ -128,6 +128,9 @@ class ClipScanner:
         (hawkeye_amd.frames) with read().  Returns the per-frame keypoints."""
         det = self._det
         out = []
+        # the caller may have produced the frames on its own stream a moment
+        # ago (rendered, decoded, copied): order the detection stream after it
+        self._detect_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._detect_stream):
             det.mog.reset()
             chunks = (self._from_source(frames) if hasattr(frames, 'read')

@@ -172,3 +172,32 @@ def test_tile_path_equals_byte_path(monkeypatch):
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_frames_produced_just_before_the_scan_are_waited_for():
+    """Clips rendered lazily on the caller's stream, right before they are
+    handed to scan_many (no synchronisation by the caller), give the events
+    of clips rendered and synchronised beforehand."""
+    from hawkeye_amd import synth
+    from hawkeye_amd.batch import ClipScanner
+    specs = [dict(width=1280, height=720, fps=60.0, balls=3 + i, frames=200,
+                  ball_r=8.0, sigma=3.0, drift=0.0, drift_hz=0.0,
+                  distractors=4, seed=7100 + i) for i in range(6)]
+    sc = ClipScanner(1280, 720, 60.0)
+    ready = [synth.ClipRenderer(s).render(0, s['frames']) for s in specs]
+    torch.cuda.synchronize()
+    want = [sc.scan(f) for f in ready]
+    del ready
+    torch.cuda.synchronize()
+
+    def lazily():
+        for s in specs:
+            yield synth.ClipRenderer(s).render(0, s['frames'])
+    got = list(sc.scan_many(lazily()))
+    sc.close()
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert len(a.events) == len(b.events)
+        for x, y in zip(a.events, b.events):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        assert np.array_equal(a.arc_params, b.arc_params)
