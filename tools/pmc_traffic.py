@@ -35,9 +35,9 @@ out = {
     'FETCH_SIZE_KiB': fetch_kib, 'WRITE_SIZE_KiB': write_kib,
     'bytes_per_launch': per_launch,
     'bytes_per_pixel_frame': per_launch / (px * 128.0),
-    # frames in, masks out, the 5 weight planes and component 0 read and
+    # frames in, masks out as 1-bit tiles, the 5 weight planes and component 0 read and
     # written; the planes of components never created are not touched
-    'expected_bytes_per_launch': (3 * 128 + 128 + 2 * 4 * (5 + 7)) * px,
+    'expected_bytes_per_launch': (3 * 128 + 128 // 8 + 2 * 4 * (5 + 7)) * px,
     'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate '
               'passes), profiles/{}_pmc_*.csv; FETCH_SIZE doubled per '
               'MI355X_MICROARCH.md (gfx950 wide reads count half)'.format(tag),
