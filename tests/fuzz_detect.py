@@ -26,6 +26,9 @@ def random_spec(rng, max_pixels):
                             64, 128, 640, 641, 639]))
         h = int(rng.choice([rng.randint(30, 160), rng.randint(160, 600),
                             48, 480, 479, 481]))
+        if rng.uniform() < 0.5:     # frames made of 32x4 tiles: the MOG
+            w = max(32, w // 32 * 32)       # kernel hands 1-bit tiles over
+            h = max(4, h // 4 * 4)
         if w * h <= max_pixels:
             break
     return dict(width=w, height=h, fps=float(rng.choice([24, 30, 60, 120])),
