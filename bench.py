@@ -264,7 +264,7 @@ def main():
         'kernel_fps': round(launch_frames / (launch_ms * 1e-3), 1),
         'note': 'the model stays on chip (registers + LDS) across the frames '
                 'of a launch and planes of components never created are not '
-                'touched, so physical traffic is ~6.6 B/px/frame (see '
+                'touched, so physical traffic is ~5.1 B/px/frame (see '
                 'traffic), not the algorithmic 324: frac > 1 is real; the '
                 'kernel is bound by VALU issue plus the divergence of waves '
                 'that hold moving-object pixels (DESIGN.md section 4)',
