@@ -13,11 +13,12 @@ out as NumPy arrays, through the same C ABI.
 
 Step 2 is GPU work (MOG + blob kernels) with a thin host loop; steps 3-4 are
 host work (multi-threaded step 3, merge / prune control flow) around small
-EM kernels.  ``scan_many`` therefore runs them as a three-stage pipeline:
-one worker thread detects the clips ahead on its own HIP stream, two more run
-step 3 of the next two clips on the host cores, and the calling thread runs
-step 4 of the earliest unfinished clip (EM kernels on a second stream).
-Results are the same as scanning the clips one by one, in the same order.
+EM kernels.  ``scan_many`` therefore runs them as a pipeline: one worker thread
+detects the clips ahead on its own HIP stream, and a pool of builder threads
+(one per spare host core) takes a detected clip each through step 3 and step 4
+(EM kernels on a stream per thread); a builder thread without a clip helps the
+step-3 builds in progress.  Results are the same as scanning the clips one by
+one, and come in the same order.
 """
 import os
 import queue
@@ -150,9 +151,12 @@ class ClipScanner:
 
     # -- steps 3-4 ---------------------------------------------------------
 
-    def build_arcs(self, per_frame, result=None):
+    def build_arcs(self, per_frame, result=None, em_stream=None):
         """Step 3 on the keypoints of one clip.  Returns (result, clip); the
-        open native clip goes to refine_arcs()."""
+        open native clip goes to refine_arcs(), whose kernels run on
+        `em_stream` (default: this scanner's EM stream)."""
+        if em_stream is None:
+            em_stream = self._em_stream
         res = result if result is not None else ClipResult()
         t0 = time.perf_counter()
         res.events = per_frame
@@ -163,7 +167,7 @@ class ClipScanner:
         clip = Clip(self.frame_width, self.frame_height, self.fps,
                     res.frame_count, res.frame, res.x, res.y, res.radius,
                     params=self.params, device=self.device,
-                    stream=self._em_stream.cuda_stream)
+                    stream=em_stream.cuda_stream)
         try:
             clip.build_initial_arcs()
         except BaseException:
@@ -207,8 +211,7 @@ class ClipScanner:
     def plan_host_stage(count=None, cores=None):
         """(clips in step 3 at a time, worker threads per clip) for a batch of
         `count` clips (None = long or unknown) on `cores` host cores (None =
-        this rank's share), two of which are left to the detection loop and
-        to step 4.
+        this rank's share), one of which is left to the detection loop.
 
         A step-3 build runs seeds speculatively ahead of its committer, and
         speculation re-does work: measured on MI355X + 16 cores (1080p60
@@ -220,23 +223,21 @@ class ClipScanner:
         (hk_step3_help) instead of owning a share of a build."""
         if cores is None:
             cores = host_core_share()
-        return max(1, cores - 2), 1
+        return max(1, cores - 1), 1
 
     def scan_many(self, clips, host_threads=None, builders=None, count=None):
         """Generator over the results of `clips` (an iterable of frame
-        tensors / sources of this scanner's size), in order.  Three stages
-        run side by side: detection of later clips (GPU, one worker thread),
-        step 3 (host cores; `builders` clips at a time, each on
-        `host_threads` worker threads) and step 4 of the earliest unfinished
-        clip (calling thread).  `count` = number of clips if `clips` cannot
-        tell (a generator); it only chooses how the host cores are split
-        (plan_host_stage) when `builders` / `host_threads` are not given."""
+        tensors / sources of this scanner's size), in order.  Detection of
+        later clips (GPU, one worker thread) runs beside steps 3-4 of earlier
+        ones (`builders` threads, a clip each; step 3 on `host_threads` worker
+        threads per clip).  `count` = number of clips if `clips` cannot tell
+        (a generator); unused today, kept for callers that pass it."""
         if count is None and hasattr(clips, '__len__'):
             count = len(clips)
         if builders is None and host_threads is None:
             builders, host_threads = self.plan_host_stage(count)
         elif builders is None:
-            builders = max(1, (host_core_share() - 2) // int(host_threads))
+            builders = max(1, (host_core_share() - 1) // int(host_threads))
         builders = max(1, int(builders))
         detected = queue.Queue(maxsize=builders)
         built = queue.Queue(maxsize=builders)
@@ -309,6 +310,11 @@ class ClipScanner:
         def build_stage():
             try:
                 torch.cuda.set_device(self.device)
+                # step 4 of a clip follows its step 3 on the same thread, on
+                # a stream of that thread: the last clips of a batch finish
+                # step 3 close together, and their step 4s then run side by
+                # side instead of queueing up on one thread
+                em_stream = torch.cuda.Stream(device=self.device)
                 while True:
                     item = next_clip()
                     if item is END:
@@ -317,15 +323,19 @@ class ClipScanner:
                     with lock:
                         building[0] += 1
                     try:
-                        done = self.build_arcs(per_frame, res)
+                        done = self.build_arcs(per_frame, res, em_stream)
                     except BaseException as exc:    # noqa: B902
                         put(built, (seq, exc))
                         return
                     finally:
                         with lock:
                             building[0] -= 1
+                    try:
+                        done = self.refine_arcs(*done)
+                    except BaseException as exc:    # noqa: B902
+                        put(built, (seq, exc))
+                        return
                     if not put(built, (seq, done)):
-                        done[1].close()
                         return
                 # every clip has been taken by some builder (END follows the
                 # last one): help those still building
@@ -338,9 +348,8 @@ class ClipScanner:
             finally:
                 put(built, END)
 
-        # leave cores to the detection loop and to step 4 while step 3 runs
-        if host_threads is None:
-            host_threads = max(1, (host_core_share() - 2) // builders)
+        if host_threads is None:    # builders given: share the cores out
+            host_threads = max(1, (host_core_share() - 1) // builders)
         nat.check(nat.lib.hk_set_host_threads(int(host_threads)))
         workers = [threading.Thread(target=detect_stage, daemon=True)] + \
             [threading.Thread(target=build_stage, daemon=True)
@@ -357,7 +366,7 @@ class ClipScanner:
                     if isinstance(item, BaseException):
                         raise item
                     want += 1
-                    yield self.refine_arcs(*item)
+                    yield item
                 if ended == builders:
                     break
                 item = built.get()
@@ -372,14 +381,4 @@ class ClipScanner:
             stop.set()
             for w in workers:
                 w.join()
-            leftovers = list(waiting.values())
-            for q in (detected, built):     # close clips nobody will refine
-                while not q.empty():
-                    item = q.get_nowait()
-                    if item is not END:
-                        leftovers.append(item[-1])
-            for item in leftovers:
-                if isinstance(item, tuple) and len(item) == 2 and \
-                        isinstance(item[1], Clip):
-                    item[1].close()
             nat.check(nat.lib.hk_set_host_threads(0))

@@ -108,10 +108,9 @@ def test_host_core_share_and_stage_plan(monkeypatch):
                         raising=False)
     assert batch.host_core_share() == 6
     plan = batch.ClipScanner.plan_host_stage
-    assert plan(None, cores=16) == (14, 1)
-    assert plan(80, cores=16) == (14, 1)
-    assert plan(4, cores=16) == (14, 1)
+    assert plan(None, cores=16) == (15, 1)
+    assert plan(4, cores=16) == (15, 1)
     for count in (None, 1, 20, 100):
         for cores in (1, 2, 3, 8, 16):
             b, t = plan(count, cores=cores)
-            assert b >= 1 and t >= 1 and b * t <= max(1, cores - 2)
+            assert b >= 1 and t >= 1 and b * t <= max(1, cores - 1)
