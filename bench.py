@@ -55,7 +55,7 @@ from hawkeye_amd import synth                   # noqa: E402
 from hawkeye_amd.batch import ClipScanner       # noqa: E402
 
 WORKLOAD = 'C_1080p60_9ball_noisy'
-CHUNK = 128
+CHUNK = int(os.environ.get('HK_BENCH_CHUNK', '128'))
 ALGO_BYTES_PER_PIXEL_FRAME = 324       # 3 in + 1 out + 160 model rd + 160 wr
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
