@@ -55,6 +55,10 @@ constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
 constexpr unsigned BAND_CAP0 = 2048;    // candidates per (frame, band) to
                                         // start with; grown on demand
 constexpr int TRACE_LDS_BYTES = 128 * 1024;
+// lanes of a border-tracing workgroup: a band holds a dozen candidates on
+// average, and every wave of the workgroup holds a wave slot (and the band's
+// LDS) for as long as the band's longest border takes
+constexpr int TRACE_THREADS = 64;
 
 struct Cand {
     uint32_t pos;           // (y << 16) | x of the start (foreground) pixel
@@ -416,7 +420,7 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
     return t;
 }
 
-__global__ __launch_bounds__(256) void blob_trace_k(
+__global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     const uint32_t *__restrict__ bits, int words_per_row, int W,
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
@@ -436,12 +440,12 @@ __global__ __launch_bounds__(256) void blob_trace_k(
     const uint32_t *fbits = bits + (long)frame * (H + 2) * words_per_row;
     const uint32_t *src = fbits + (long)(row0 + 1) * words_per_row;
 #pragma unroll 8
-    for (int i = threadIdx.x; i < nrows * words_per_row; i += 256)
+    for (int i = threadIdx.x; i < nrows * words_per_row; i += TRACE_THREADS)
         band_lds[i] = src[i];
     __syncthreads();
     const BandImg img{band_lds, words_per_row, row0, fbits, W, H};
 
-    for (unsigned i = threadIdx.x; i < n; i += 256) {
+    for (unsigned i = threadIdx.x; i < n; i += TRACE_THREADS) {
         const Cand c = cands[(size_t)bucket * band_cap + i];
         const int x0 = (int)(c.pos & 0xFFFFu), y0 = (int)(c.pos >> 16);
         const bool hole = (c.fh & 1u) != 0u;
@@ -856,7 +860,8 @@ static int launch_batch(hk_blob *b, int nframes) {
                            b->band_cap);
         HK_LAUNCH_CHECK("blob_scan_k");
     }
-    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(256), b->trace_lds,
+    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(TRACE_THREADS),
+                       b->trace_lds,
                        s, b->bits, b->words_per_row, b->width, b->height,
                        b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
                        b->pts, b->cap_blob, b->dev, b->band_cap);
