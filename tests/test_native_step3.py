@@ -206,3 +206,29 @@ def test_helper_threads_do_not_change_the_result():
     finally:
         nat.check(nat.lib.hk_set_host_threads(0))
     assert nat.lib.hk_step3_help(100) == 0      # nothing to help with
+
+
+def test_random_tag_sets_match_oracle():
+    """A short run of tests/fuzz_arcs.py (step 3 only, host code): random
+    geometries, frame rates, ball counts, clutter and distractor tracks; the
+    oracle rounds its powers like the native code (see em_ref), which leaves
+    only the logic to compare."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        'fuzz_arcs.py')
+    spec = importlib.util.spec_from_file_location('fuzz_arcs', path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from oracle import em_ref
+    try:
+        rng = np.random.RandomState(2024)
+        done = 0
+        while done < 3:
+            case, meas = fz.random_case(rng)
+            if sum(len(v) for v in meas.values()) > 1500:
+                continue            # keep the Python oracle to seconds
+            err = fz.compare(case, meas, False)
+            assert err is None, (err, case)
+            done += 1
+    finally:
+        em_ref.POWERS_AS_PRODUCTS = False
