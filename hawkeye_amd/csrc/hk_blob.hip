@@ -52,13 +52,20 @@ namespace {
 constexpr int MAXPTS = 256;             // hard cap on a traced contour
 constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
 constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
-constexpr unsigned BAND_CAP0 = 2048;    // candidates per (frame, band) to
+constexpr unsigned BAND_CAP0 = 512;     // candidates per (frame, band, block) to
                                         // start with; grown on demand
 constexpr int TRACE_LDS_BYTES = 128 * 1024;
 // lanes of a border-tracing workgroup: a band holds a dozen candidates on
 // average, and every wave of the workgroup holds a wave slot (and the band's
 // LDS) for as long as the band's longest border takes
 constexpr int TRACE_THREADS = 64;
+// A tracing workgroup works on the candidates of a block of COL_WORDS words
+// of a band and holds a window of WIN_WORDS words per row in LDS: the block
+// plus COL_MARGIN words (128 pixels) on either side.  A closed border of at
+// most max_pts <= 256 points stays within max_pts / 2 pixels of its start in
+// every direction, and a trace that goes further is given up.
+constexpr int COL_WORDS = 8, COL_MARGIN = 4;
+constexpr int WIN_WORDS = COL_WORDS + 2 * COL_MARGIN;
 
 struct Cand {
     uint32_t pos;           // (y << 16) | x of the start (foreground) pixel
@@ -132,7 +139,8 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     const uint8_t *__restrict__ masks, long frame_stride, long pitch, int W,
     int H, int nframes, int segs, bool vec, Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, int band_rows, int nbands,
-    unsigned short *__restrict__ bits, int words_per_row, unsigned band_cap) {
+    unsigned short *__restrict__ bits, int words_per_row, unsigned band_cap,
+    int ncols) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)nframes * H * segs;
     if (tid >= total) return;
@@ -162,11 +170,14 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     unsigned hole = ~(cur17 >> 1) & cur17 & (up18 >> 1) & valid;
     if (nonbinary) atomicOr(&ctr[CTR_FLAGS], FLAG_NONBINARY);
 
-    // candidates go to the list of their (frame, band of rows); few 16-pixel
-    // segments hold any, so one atomic per such segment is cheap
+    // candidates go to the list of their (frame, band of rows, block of
+    // columns); few 16-pixel segments hold any, so one atomic per such
+    // segment is cheap
     const unsigned c = __popc(outer) + __popc(hole);
     if (c == 0) return;
-    const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
+    const unsigned bucket =
+        ((unsigned)f * nbands + (unsigned)(y / band_rows)) * ncols +
+        (unsigned)(x0 / (32 * COL_WORDS));
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
     if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
     Cand *list = cands + (size_t)bucket * band_cap;
@@ -213,10 +224,12 @@ __device__ __forceinline__ unsigned plane_row(unsigned p01, unsigned p23,
 
 __device__ __forceinline__ void emit_candidates(
     unsigned outer, unsigned hole, int f, int y, int x0, Cand *cands,
-    unsigned *ctr, int band_rows, int nbands, unsigned band_cap) {
+    unsigned *ctr, int band_rows, int nbands, unsigned band_cap, int ncols) {
     const unsigned c = __popc(outer) + __popc(hole);
     if (c == 0) return;
-    const unsigned bucket = (unsigned)f * nbands + (unsigned)(y / band_rows);
+    const unsigned bucket =
+        ((unsigned)f * nbands + (unsigned)(y / band_rows)) * ncols +
+        (unsigned)(x0 / (32 * COL_WORDS));
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
     if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
     Cand *list = cands + (size_t)bucket * band_cap;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
     const uint4 *__restrict__ tiles, int tiles_x, int tiles_y, int nframes,
     int H, uint32_t *__restrict__ bits, int words_per_row,
     Cand *__restrict__ cands, unsigned *__restrict__ ctr, int band_rows,
-    int nbands, unsigned band_cap) {
+    int nbands, unsigned band_cap, int ncols) {
     const long per_frame = (long)tiles_x * tiles_y;
     const long total = (long)nframes * per_frame;
     for (long tid = (long)blockIdx.x * 256 + threadIdx.x; tid < total;
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
             const unsigned outer = cur & ~w & ~n & ~nw & ~ne;
             const unsigned hole = ~cur & w & n;
             emit_candidates(outer, hole, f, ty * 4 + r, tx * 32, cands, ctr,
-                            band_rows, nbands, band_cap);
+                            band_rows, nbands, band_cap, ncols);
             n = cur;
             n_left31 = left31;
             n_right0 = right0;
@@ -298,10 +311,10 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
 // dependent read of the 3x3 neighbourhood: from the byte image in HBM that is
 // 8 scattered loads and a memory round trip per step, here six LDS reads.
 struct BandImg {
-    const uint32_t *rows;   // LDS
-    int wpr, row0;
+    const uint32_t *rows;   // LDS: WIN_WORDS words per row
+    int w0, row0;           // first word (padded frame) and image row held
     const uint32_t *frame;  // the padded frame in global memory (for fg())
-    int W, H;
+    int wpr, W, H;
 
     __device__ __forceinline__ unsigned fg(int x, int y) const {
         if (x < 0 || x >= W || y < 0 || y >= H) return 0u;
@@ -309,7 +322,8 @@ struct BandImg {
     }
     // bits x-1, x, x+1 of image row y
     __device__ __forceinline__ unsigned three(int x, int y) const {
-        const uint32_t *q = rows + (y - row0) * wpr + 1 + ((x - 1) >> 5);
+        const uint32_t *q =
+            rows + (y - row0) * WIN_WORDS + 1 + ((x - 1) >> 5) - w0;
         const unsigned long long v =
             (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
         return (unsigned)(v >> ((x - 1) & 31)) & 7u;
@@ -413,6 +427,7 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
         x3 = x4;
         y3 = y4;
         if (y3 - y0 > max_pts / 2) return t;
+        if (x3 - x0 > max_pts / 2 || x0 - x3 > max_pts / 2) return t;
         s = (s + 4) & 7;
         nb = img.ring(x3, y3);
     }
@@ -425,25 +440,31 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
     ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm,
-    unsigned band_cap) {
+    unsigned band_cap, int ncols) {
     extern __shared__ uint32_t band_lds[];
     const unsigned bucket = blockIdx.x;
     unsigned n = ctr[CTR_WORDS + bucket];
     if (n == 0) return;                     // workgroup-uniform
     if (n > band_cap) n = band_cap;
-    const int frame = (int)(bucket / (unsigned)nbands);
-    const int band = (int)(bucket % (unsigned)nbands);
-    // image rows band*band_rows - 1 .. + band_rows + max_pts/2 + 1
+    const int col = (int)(bucket % (unsigned)ncols);
+    const unsigned fb = bucket / (unsigned)ncols;
+    const int frame = (int)(fb / (unsigned)nbands);
+    const int band = (int)(fb % (unsigned)nbands);
+    // image rows band*band_rows - 1 .. + band_rows + max_pts/2 + 1, words
+    // w0 .. w0 + WIN_WORDS - 1 of the padded rows (zeros outside the frame)
     const int row0 = band * band_rows - 1;
     int nrows = band_rows + prm.max_pts / 2 + 3;
     if (row0 + nrows > H + 1) nrows = H + 1 - row0;
+    const int w0 = 1 + col * COL_WORDS - COL_MARGIN;
     const uint32_t *fbits = bits + (long)frame * (H + 2) * words_per_row;
     const uint32_t *src = fbits + (long)(row0 + 1) * words_per_row;
-#pragma unroll 8
-    for (int i = threadIdx.x; i < nrows * words_per_row; i += TRACE_THREADS)
-        band_lds[i] = src[i];
+    for (int i = threadIdx.x; i < nrows * WIN_WORDS; i += TRACE_THREADS) {
+        const int r = i / WIN_WORDS, w = w0 + (i - r * WIN_WORDS);
+        band_lds[i] = w >= 0 && w < words_per_row
+                          ? src[(long)r * words_per_row + w] : 0u;
+    }
     __syncthreads();
-    const BandImg img{band_lds, words_per_row, row0, fbits, W, H};
+    const BandImg img{band_lds, w0, row0, fbits, words_per_row, W, H};
 
     for (unsigned i = threadIdx.x; i < n; i += TRACE_THREADS) {
         const Cand c = cands[(size_t)bucket * band_cap + i];
@@ -656,7 +677,8 @@ struct hk_blob {
     DevParams dev;
     int n_thresholds = 0;
     unsigned cap_blob = 0, eager = 0;
-    int band_rows = 0, nbands = 0;      // K3 works on bands of rows
+    int band_rows = 0, nbands = 0;      // K3 works on bands of rows,
+    int ncols = 0;                      // in blocks of COL_WORDS words
     size_t trace_lds = 0;               // bytes of LDS a K3 workgroup needs
     Cand *cands = nullptr;
     unsigned *ctr = nullptr;
@@ -746,11 +768,15 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
                                        (double)params->maxArea /
                                        (double)params->minCircularity);
     const int max_pts = (int)std::floor(max_perim) + 3;
-    if (max_pts > MAXPTS)
+    // (the tracer's LDS window reaches 32 * COL_MARGIN pixels beyond its
+    // block of columns, and a border strays max_pts / 2 from its start)
+    constexpr int MAX_PTS_OK =
+        MAXPTS < 2 * (32 * COL_MARGIN - 2) ? MAXPTS : 2 * (32 * COL_MARGIN - 2);
+    if (max_pts > MAX_PTS_OK)
         return hk::fail(HK_ERR_ARG,
                         "hk_blob_create: maxArea/minCircularity allow "
                         "contours of %d points, more than the %d supported",
-                        max_pts, MAXPTS);
+                        max_pts, MAX_PTS_OK);
     hk::DeviceGuard guard(device);
     if (!guard.ok)
         return hk::fail(HK_ERR_HIP, "hk_blob_create: cannot select device %d",
@@ -771,24 +797,18 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     for (double t = params->minThreshold; t < params->maxThreshold;
          t += params->thresholdStep)
         ++b->n_thresholds;
-    // K3 holds band_rows + max_pts/2 + 3 rows of the 1-bit image in LDS
+    // K3 holds band_rows + max_pts/2 + 3 rows of a WIN_WORDS-wide window of
+    // the 1-bit image in LDS (11 KB for Hawkeye's parameters)
     b->words_per_row = (width + 31) / 32 + 2;
     {
-        const int row_bytes = 4 * b->words_per_row;
         const int extra = max_pts / 2 + 3;
-        const int fit = TRACE_LDS_BYTES / row_bytes - extra;
-        if (fit < 8) {
-            delete b;
-            return hk::fail(HK_ERR_ARG,
-                            "hk_blob_create: frames wider than %d pixels are "
-                            "not supported",
-                            (TRACE_LDS_BYTES / (4 * (extra + 8)) - 2) * 32);
-        }
-        b->band_rows = std::min(std::min(fit, 64), height);
+        b->band_rows = std::min(64, height);
         b->nbands = (height + b->band_rows - 1) / b->band_rows;
-        b->trace_lds = (size_t)row_bytes * (b->band_rows + extra);
+        b->ncols = ((width + 31) / 32 + COL_WORDS - 1) / COL_WORDS;
+        // (+1 word: the 64-bit read of a row's last word looks one ahead)
+        b->trace_lds = (size_t)4 * (WIN_WORDS * (b->band_rows + extra) + 1);
     }
-    const size_t nbuckets = (size_t)max_frames * b->nbands;
+    const size_t nbuckets = (size_t)max_frames * b->nbands * b->ncols;
     b->cap_blob = (unsigned)max_frames * 128u;
     b->eager = std::min(b->cap_blob, (unsigned)max_frames * 48u);
 
@@ -832,7 +852,7 @@ static int launch_batch(hk_blob *b, int nframes) {
     const uint8_t *masks = b->masks;
     const long frame_stride = b->frame_stride, pitch = b->pitch;
 
-    const unsigned nbuckets = (unsigned)nframes * b->nbands;
+    const unsigned nbuckets = (unsigned)nframes * b->nbands * b->ncols;
     HK_HIP(hipMemsetAsync(b->ctr, 0,
                           sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
     if (!masks) {               // the MOG kernel's 1-bit tiles
@@ -845,7 +865,8 @@ static int launch_batch(hk_blob *b, int nframes) {
         hipLaunchKernelGGL(blob_scan_tiles_k, dim3(blocks), dim3(256), 0, s,
                            (const uint4 *)b->tiles, tiles_x, tiles_y, nframes,
                            b->height, b->bits, b->words_per_row, b->cands,
-                           b->ctr, b->band_rows, b->nbands, b->band_cap);
+                           b->ctr, b->band_rows, b->nbands, b->band_cap,
+                           b->ncols);
         HK_LAUNCH_CHECK("blob_scan_tiles_k");
     } else {
         const int segs = (b->width + 15) / 16;
@@ -857,14 +878,14 @@ static int launch_batch(hk_blob *b, int nframes) {
                            b->width, b->height, nframes, segs, vec, b->cands,
                            b->ctr, b->band_rows, b->nbands,
                            (unsigned short *)b->bits, b->words_per_row,
-                           b->band_cap);
+                           b->band_cap, b->ncols);
         HK_LAUNCH_CHECK("blob_scan_k");
     }
     hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(TRACE_THREADS),
                        b->trace_lds,
                        s, b->bits, b->words_per_row, b->width, b->height,
                        b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
-                       b->pts, b->cap_blob, b->dev, b->band_cap);
+                       b->pts, b->cap_blob, b->dev, b->band_cap, b->ncols);
     HK_LAUNCH_CHECK("blob_trace_k");
     hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts);
@@ -953,10 +974,11 @@ extern "C" int hk_blob_enqueue_tiles(hk_blob *b, int nframes, void *stream) {
 // the contour buffers (4x: how many contours pass the filters is only known
 // once every candidate has been traced), then runs the batch again.
 static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
-    const size_t nbuckets_max = (size_t)b->max_frames * b->nbands;
+    const size_t nbuckets_max =
+        (size_t)b->max_frames * b->nbands * b->ncols;
     HK_HIP(hipStreamSynchronize(b->stream));
     if (band_full) {
-        const size_t nb = (size_t)nframes * b->nbands;
+        const size_t nb = (size_t)nframes * b->nbands * b->ncols;
         b->h_counts.resize(nb);
         HK_HIP(hipMemcpy(b->h_counts.data(), b->ctr + CTR_WORDS,
                          sizeof(unsigned) * nb, hipMemcpyDeviceToHost));

@@ -287,7 +287,7 @@ class EventDetector:
         self._side = torch.cuda.Stream(device=self.device)
         self._mog_done = [torch.cuda.Event() for _ in range(self.DEPTH)]
 
-    DEPTH = 3
+    DEPTH = int(os.environ.get('HK_DETECT_DEPTH', '3'))
 
     def submit(self, frames):
         t = frames.shape[0]
