@@ -122,6 +122,36 @@ def from_host_rate(scanner, spec, frames_dev, nframes, device):
                     'through hawkeye_amd.frames.PinnedHostSource'}
 
 
+def mog_alone_ms(scanner, frames):
+    """Average duration of full-chunk MOG launches over the clip with the
+    GPU to themselves, HIP events on the launch stream."""
+    det = scanner.detector
+    full = frames.shape[0] // CHUNK
+    if full == 0:
+        return None
+    det.mog.reset()
+    masks = None
+    if not det.use_tiles:
+        masks = torch.empty((CHUNK, frames.shape[1], frames.shape[2]),
+                            dtype=torch.uint8, device=frames.device)
+
+    def launch(s):
+        if det.use_tiles:
+            det.mog.apply_batch_tiles(frames[s:s + CHUNK], det._tiles[0])
+        else:
+            det.mog.apply_batch(frames[s:s + CHUNK], out=masks)
+    launch(0)                                   # model and launch order set up
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(1, full):
+        launch(k * CHUNK)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / max(1, full - 1) if full > 1 else None
+
+
 def traffic_from_profiles():
     """Per-launch HBM bytes of mog_batch2_k from the committed PMC summary
     (profiles/mog_traffic.json, written by tools/pmc_traffic.py), or None."""
@@ -215,6 +245,11 @@ def main():
     mog_frames = [n for _, _, n in scanner.detector.mog_timing]
     scanner.detector.mog_timing = None
 
+    # the same launches with nothing else on the GPU (no blob kernels of the
+    # previous chunk in their way): the kernel's own duration, which is what
+    # rocprofv3's kernel trace reports
+    alone_ms = mog_alone_ms(scanner, frames) if rank == 0 else None
+
     per_frame, arc_params = result.events, result.arc_params
     tags_left, tilt = int(result.alive.sum()), result.camera_tilt
     # collect every rank's arc table on rank 0 (RCCL), and the slowest time
@@ -258,11 +293,18 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'traffic': None if traffic is None else traffic.get('bytes_per_launch'),
         'launch_ms': round(launch_ms, 4),
+        'launch_ms_alone': None if alone_ms is None else round(alone_ms, 4),
         'frames_per_launch': int(launch_frames),
         'algorithmic_bytes_per_launch': int(ALGO_BYTES_PER_PIXEL_FRAME * px *
                                             launch_frames),
         'kernel_fps': round(launch_frames / (launch_ms * 1e-3), 1),
-        'note': 'the model stays on chip (registers + LDS) across the frames '
+        'note': 'launch_ms = HIP events around the launches of the timed '
+                'region, on their stream: it includes the time a queued launch '
+                'waits behind the previous chunk\'s blob kernels; '
+                'launch_ms_alone = the same launches with the GPU to '
+                'themselves, which is what rocprofv3\'s kernel duration '
+                '(profiles/r01_kernel_stats.csv) shows.  '
+                'The model stays on chip (registers + LDS) across the frames '
                 'of a launch and planes of components never created are not '
                 'touched, so physical traffic is ~5.1 B/px/frame (see '
                 'traffic), not the algorithmic 324: frac > 1 is real; the '
