@@ -14,9 +14,9 @@ seed) -- the clip-sharded layout of configs[4] -- and the per-rank arc tables
 are gathered to rank 0 over RCCL; value = all frames of all ranks / max time.
 
 The K timed steps run the way a batch of clips runs in production
-(hawkeye_amd.batch.ClipScanner.scan_many): as a two-stage pipeline in which
-the GPU detects pass k+2 while the host cores run step 3 of pass k+1 and
-step 4 of pass k.
+(hawkeye_amd.batch.ClipScanner.scan_many): the GPU detects pass k+1, k+2 ...
+while the host cores run steps 3-4 of the passes before (one builder thread
+per pass, 15 at a time on a 16-core share).
 Every pass does all of the work, and nothing is cached between passes.  The
 latency of one clip on its own (no overlap) is reported as `single_clip_ms`.
 
@@ -328,9 +328,9 @@ def main():
                    'clips': world, 'sharding': 'one clip per GPU, arc tables '
                    'gathered to rank 0 over RCCL' if world > 1 else 'single GPU',
                    'detect_chunk_frames': CHUNK},
-        'pipeline': 'three stages side by side: detection of pass k+2 '
-                    '(GPU), step 3 of pass k+1 (host cores), step 4 of pass '
-                    'k; every pass does all the work',
+        'pipeline': 'detection of the passes ahead (GPU) beside steps 3-4 '
+                    'of the passes before (one host thread per pass); every '
+                    'pass does all the work',
         'stage_ms_per_step': {k: round(v / args.steps * 1e3, 3)
                               for k, v in stage_s.items()},
         'single_clip_ms': None if single_ms is None else round(single_ms, 3),
