@@ -75,7 +75,7 @@ def check_against_oracle(masks, params_height=None):
     return n_c, n_k
 
 
-@pytest.mark.parametrize('h,w', [(96, 128), (61, 83), (480, 640)])
+@pytest.mark.parametrize('h,w', [(96, 128), (61, 83), (480, 640), (70, 8200)])
 def test_shapes_match_oracle(h, w):
     rng = np.random.RandomState(h + w)
     masks = np.stack([mask_shapes(rng, h, w) for _ in range(12)])
