@@ -344,7 +344,7 @@ public:
         if (nthreads_ == 1) want = 1;
         // helpers may join a full pass: leave them room to run ahead
         const bool joinable = maxcount <= 0 && n_ >= 1024;
-        if (joinable) want = std::max(want, (size_t)(per_thread * 4));
+        if (joinable) want = std::max(want, (size_t)(per_thread * MAX_SEED_THREADS));
         window_ = 1;
         while (window_ < want) window_ <<= 1;
         slots_.reset(new Slot[window_]);
