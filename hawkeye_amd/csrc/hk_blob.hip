@@ -40,9 +40,12 @@
 // uncontracted, so results equal the oracle's bit for bit.
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "hk_common.h"
@@ -370,7 +373,8 @@ __device__ __forceinline__ unsigned before_ring(int x, int y, int rx, int ry) {
 // / (hole) examines no background pixel before (x0 + 1, y0).  A border that
 // reaches a row more than max_pts / 2 below its start cannot close within
 // max_pts points (a step changes the row by at most one), so it is given up
-// there: no pixel below row y0 + max_pts / 2 + 1 is ever read.
+// there: no pixel below row y0 + max_pts / 2 + 1 is ever read (and none above
+// row y0 - 2: see the checks after each step).
 template <bool WRITE, class Image>
 __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
                                int max_pts, ushort2 *__restrict__ pts) {
@@ -412,7 +416,6 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
         s = (first + skip) & 7;
         const int x4 = x3 + dir_dx(s), y4 = y3 + dir_dy(s);
 
-        if (!hole && before(x3, y3, rx, ry)) return t;
         if (t.npts >= max_pts) return t;
         if (WRITE) pts[t.npts] = make_ushort2((unsigned short)x3, (unsigned short)y3);
         ++t.npts;
@@ -426,6 +429,14 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
         x3 = x4;
         y3 = y4;
+        // An outer border that reaches a pixel before its start in raster
+        // order is not traced from its first pixel.  A hole's pixels all lie
+        // in rows >= y0 if (x0 + 1, y0) is its first, and its border within
+        // one pixel of them: a hole border that climbs above row y0 - 1
+        // belongs to a hole that starts further up.  Either way the candidate
+        // retires here, before the neighbourhood of (x3, y3) is read: no
+        // pixel above row y0 - 2 is ever read.
+        if (hole ? y3 < y0 - 1 : before(x3, y3, rx, ry)) return t;
         if (y3 - y0 > max_pts / 2) return t;
         if (x3 - x0 > max_pts / 2 || x0 - x3 > max_pts / 2) return t;
         s = (s + 4) & 7;
@@ -450,18 +461,20 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     const unsigned fb = bucket / (unsigned)ncols;
     const int frame = (int)(fb / (unsigned)nbands);
     const int band = (int)(fb % (unsigned)nbands);
-    // image rows band*band_rows - 1 .. + band_rows + max_pts/2 + 1, words
-    // w0 .. w0 + WIN_WORDS - 1 of the padded rows (zeros outside the frame)
-    const int row0 = band * band_rows - 1;
-    int nrows = band_rows + prm.max_pts / 2 + 3;
+    // image rows band*band_rows - 2 .. + band_rows + max_pts/2 + 1 (a border
+    // that starts on the band's first row y0 steps up to row y0 - 1 at most,
+    // and the neighbourhood read there reaches row y0 - 2), words w0 .. w0 +
+    // WIN_WORDS - 1 of the padded rows; zeros outside the padded frame
+    const int row0 = band * band_rows - 2;
+    int nrows = band_rows + prm.max_pts / 2 + 4;
     if (row0 + nrows > H + 1) nrows = H + 1 - row0;
     const int w0 = 1 + col * COL_WORDS - COL_MARGIN;
     const uint32_t *fbits = bits + (long)frame * (H + 2) * words_per_row;
-    const uint32_t *src = fbits + (long)(row0 + 1) * words_per_row;
     for (int i = threadIdx.x; i < nrows * WIN_WORDS; i += TRACE_THREADS) {
         const int r = i / WIN_WORDS, w = w0 + (i - r * WIN_WORDS);
-        band_lds[i] = w >= 0 && w < words_per_row
-                          ? src[(long)r * words_per_row + w] : 0u;
+        const int prow = row0 + r + 1;          // row of the padded frame
+        band_lds[i] = prow >= 0 && prow < H + 2 && w >= 0 && w < words_per_row
+                          ? fbits[(long)prow * words_per_row + w] : 0u;
     }
     __syncthreads();
     const BandImg img{band_lds, w0, row0, fbits, words_per_row, W, H};
@@ -797,11 +810,11 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     for (double t = params->minThreshold; t < params->maxThreshold;
          t += params->thresholdStep)
         ++b->n_thresholds;
-    // K3 holds band_rows + max_pts/2 + 3 rows of a WIN_WORDS-wide window of
+    // K3 holds band_rows + max_pts/2 + 4 rows of a WIN_WORDS-wide window of
     // the 1-bit image in LDS (11 KB for Hawkeye's parameters)
     b->words_per_row = (width + 31) / 32 + 2;
     {
-        const int extra = max_pts / 2 + 3;
+        const int extra = max_pts / 2 + 4;
         b->band_rows = std::min(64, height);
         b->nbands = (height + b->band_rows - 1) / b->band_rows;
         b->ncols = ((width + 31) / 32 + COL_WORDS - 1) / COL_WORDS;
@@ -970,6 +983,8 @@ extern "C" int hk_blob_enqueue_tiles(hk_blob *b, int nframes, void *stream) {
     return HK_OK;
 }
 
+static int wait_done(hk_blob *b);
+
 // Grows the candidate lists (to the largest per-band count of the batch) and
 // the contour buffers (4x: how many contours pass the filters is only known
 // once every candidate has been traced), then runs the batch again.
@@ -1009,8 +1024,43 @@ static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
     }
     const int rc = launch_batch(b, nframes);
     if (rc != HK_OK) return rc;
-    HK_HIP(hipEventSynchronize(b->done));
-    return HK_OK;
+    return wait_done(b);
+}
+
+// Waits for the batch's `done` event, but not for ever: a batch is a few
+// hundred microseconds of GPU work behind at most a few MOG launches, so an
+// event that has not fired after HK_BLOB_WAIT_S seconds (default 60) means
+// the work in front of it is stuck (a stream dependency that cannot resolve,
+// a faulted queue).  The caller then gets HK_ERR_HIP instead of a thread that
+// never returns.
+static int wait_done(hk_blob *b) {
+    static const double limit_s = [] {
+        const char *e = getenv("HK_BLOB_WAIT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 60.0;
+    }();
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    for (long spins = 0;; ++spins) {
+        const hipError_t e = hipEventQuery(b->done);
+        if (e == hipSuccess) return HK_OK;
+        if (e != hipErrorNotReady)
+            return hk::fail(HK_ERR_HIP, "hk_blob: hipEventQuery: %s",
+                            hipGetErrorString(e));
+        if (spins < 200) continue;              // ~ the first 100 us: spin
+        const double waited =
+            std::chrono::duration<double>(clock::now() - t0).count();
+        if (waited > limit_s)
+            return hk::fail(HK_ERR_HIP,
+                            "hk_blob: the batch did not finish within %.0f s "
+                            "(stream %p); GPU work in front of it is stuck",
+                            limit_s, (void *)b->stream);
+        // a batch normally ends within a MOG launch (< 1 ms): stay on the
+        // core for a few of those, then get out of the way
+        if (waited < 0.003) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(
+                 waited < 0.1 ? 50 : 1000));
+    }
 }
 
 // Waits for the batch and returns the surviving contours per frame in the
@@ -1028,7 +1078,10 @@ static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
     hk::DeviceGuard guard(b->device);
     const int nframes = b->pending_frames;
     b->pending_frames = 0;
-    HK_HIP(hipEventSynchronize(b->done));
+    {
+        const int rc = wait_done(b);
+        if (rc != HK_OK) return rc;
+    }
     if (b->h_ctr[CTR_FLAGS] & FLAG_NONBINARY)
         return hk::fail(HK_ERR_ARG,
                         "hk_blob: mask holds values other than 0 and 255");

@@ -22,6 +22,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -703,6 +704,19 @@ __global__ __launch_bounds__(256) void mog_math_check_k(
 // host side
 // ---------------------------------------------------------------------------
 
+// constants exactly as bgfg_gaussmix.cpp derives them
+static MogConst opencv_defaults() {
+    const double noiseSigma = 30 * 0.5;
+    MogConst c;
+    c.T = (float)0.7;
+    c.vT = (float)(2.5 * 2.5);
+    c.w0 = (float)0.05;
+    c.sk0 = (float)(c.w0 / (noiseSigma * 2 * std::sqrt(3.)));
+    c.var0 = (float)(noiseSigma * noiseSigma * 4);
+    c.minVar = (float)(noiseSigma * noiseSigma);
+    return c;
+}
+
 struct hk_mog {
     int width = 0, height = 0, device = 0;
     long n_pixels = 0;
@@ -729,14 +743,7 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
     m->height = height;
     m->device = device;
     m->n_pixels = (long)width * height;
-    // constants exactly as bgfg_gaussmix.cpp derives them
-    const double noiseSigma = 30 * 0.5;
-    m->c.T = (float)0.7;
-    m->c.vT = (float)(2.5 * 2.5);
-    m->c.w0 = (float)0.05;
-    m->c.sk0 = (float)(m->c.w0 / (noiseSigma * 2 * std::sqrt(3.)));
-    m->c.var0 = (float)(noiseSigma * noiseSigma * 4);
-    m->c.minVar = (float)(noiseSigma * noiseSigma);
+    m->c = opencv_defaults();
 
     const size_t bytes = sizeof(float) * NPLANES * (size_t)m->n_pixels;
     hipError_t e = hipMalloc((void **)&m->planes, bytes);
@@ -792,71 +799,83 @@ extern "C" int hk_mog_reset(hk_mog *m, void *stream) {
 
 extern "C" int hk_mog_nframes(const hk_mog *m) { return m ? m->nframes : 0; }
 
+// What one batch launch works on: the model, the alpha table and the launch
+// order bookkeeping (cost / order, see mog_order_k).  hk_mog keeps these in
+// buffers of its own; hk_mog_apply_batch_static takes the model from the
+// caller and the rest from the library's static device array.
+struct MogTarget {
+    int width, height;
+    long n_pixels;
+    float *planes;
+    const float *alpha_table;
+    int *cost, *order;          // may be null: no launch order kept
+    int n_groups;
+    int *frames_of_cost;        // host: frames of the launch that wrote cost[]
+    int frames_before;
+    const MogConst *c;
+};
+
 // mask_dev and tiles_dev: either may be null, not both (tiles only with the
 // tiled kernel).
-static int apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
-                       long bgr_pitch, void *mask_dev, long mask_frame_stride,
-                       long mask_pitch, void *tiles_dev, int nframes,
-                       void *stream) {
-    if (!m || !bgr_dev || (!mask_dev && !tiles_dev))
-        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: null argument");
+static int launch_batch(const MogTarget &m, const void *bgr_dev,
+                        long bgr_frame_stride, long bgr_pitch, void *mask_dev,
+                        long mask_frame_stride, long mask_pitch,
+                        void *tiles_dev, int nframes, hipStream_t s) {
     if (!mask_dev) {            // tiles only: no mask geometry to check
-        mask_pitch = m->width;
-        mask_frame_stride = (long)m->width * m->height;
+        mask_pitch = m.width;
+        mask_frame_stride = (long)m.width * m.height;
     }
     if (nframes < 0)
         return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: nframes %d", nframes);
     if (nframes == 0) return HK_OK;
-    if (bgr_pitch < 3L * m->width || mask_pitch < m->width)
+    if (bgr_pitch < 3L * m.width || mask_pitch < m.width)
         return hk::fail(HK_ERR_ARG,
                         "hk_mog_apply_batch: pitch too small (bgr %ld, mask "
-                        "%ld) for width %d", bgr_pitch, mask_pitch, m->width);
-    if (nframes > 1 && (bgr_frame_stride < bgr_pitch * m->height ||
-                        mask_frame_stride < mask_pitch * m->height))
+                        "%ld) for width %d", bgr_pitch, mask_pitch, m.width);
+    if (nframes > 1 && (bgr_frame_stride < bgr_pitch * m.height ||
+                        mask_frame_stride < mask_pitch * m.height))
         return hk::fail(HK_ERR_ARG,
                         "hk_mog_apply_batch: frame stride smaller than a "
                         "frame");
-    hk::DeviceGuard guard(m->device);
-    const hipStream_t s = (hipStream_t)stream;
-    const long N = m->n_pixels;
+    const long N = m.n_pixels;
     const bool fast =
-        bgr_pitch == 3L * m->width && mask_pitch == m->width && N % 2 == 0 &&
+        bgr_pitch == 3L * m.width && mask_pitch == m.width && N % 2 == 0 &&
         ((uintptr_t)bgr_dev & 1) == 0 && ((uintptr_t)mask_dev & 1) == 0 &&
         (nframes == 1 ||
          (bgr_frame_stride % 2 == 0 && mask_frame_stride % 2 == 0));
     if (fast) {
-        const unsigned blocks = (unsigned)((m->n_groups + 7) / 8) * 8 * 4;
+        const unsigned blocks = (unsigned)((m.n_groups + 7) / 8) * 8 * 4;
         // short launches stream the model (HBM-bound), long ones are
         // bound by the latency of the frame loads and by arithmetic: see
         // mog_batch2_k
 #define HK_MOG_LAUNCH(W, D, TL)                                               \
         hipLaunchKernelGGL((mog_batch2_k<W, D, TL>), dim3(blocks), dim3(64),  \
-                           0, s, m->planes, N, m->width,                      \
+                           0, s, m.planes, N, m.width,                        \
                            (const uint8_t *)bgr_dev,                          \
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
-                           mask_frame_stride, nframes, m->nframes,            \
-                           m->alpha_table, m->c, m->n_groups, order, cost,    \
+                           mask_frame_stride, nframes, m.frames_before,       \
+                           m.alpha_table, *m.c, m.n_groups, order, cost,      \
                            (unsigned *)tiles_dev, tile_words)
-        const bool tileable = m->width % 32 == 0 && m->height % 4 == 0;
+        const bool tileable = m.width % 32 == 0 && m.height % 4 == 0;
         const long tile_words = (N / 128) * 4;
         if (tiles_dev && !tileable)
             return hk::fail(HK_ERR_ARG,
                             "hk_mog_apply_batch_tiles: %dx%d frames are not "
-                            "made of 32x4 tiles", m->width, m->height);
+                            "made of 32x4 tiles", m.width, m.height);
         // batches are launched slowest groups first (cost of the previous
         // batch); single frames are not worth the bookkeeping
         const int *order = nullptr;
         int *cost = nullptr;
-        if (nframes > 4) {
-            cost = m->cost;
-            if (m->frames_of_cost > 0) {
+        if (nframes > 4 && m.cost) {
+            cost = m.cost;
+            if (*m.frames_of_cost > 0) {
                 hipLaunchKernelGGL(mog_order_k, dim3(1), dim3(1024), 0, s,
-                                   m->cost, m->order, m->n_groups,
-                                   m->frames_of_cost);
+                                   m.cost, m.order, m.n_groups,
+                                   *m.frames_of_cost);
                 HK_LAUNCH_CHECK("mog_order_k");
-                order = m->order;
+                order = m.order;
             }
-            m->frames_of_cost = nframes;
+            *m.frames_of_cost = nframes;
         }
         if (nframes <= 4) {
             if (tileable) HK_MOG_LAUNCH(4, 1, true);
@@ -874,13 +893,30 @@ static int apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
                             "2-byte aligned frames");
         const unsigned blocks = (unsigned)((N + 255) / 256);
         hipLaunchKernelGGL(mog_batch1_k, dim3(blocks), dim3(256), 0, s,
-                           m->planes, N, m->width, (const uint8_t *)bgr_dev,
+                           m.planes, N, m.width, (const uint8_t *)bgr_dev,
                            bgr_frame_stride, bgr_pitch, (uint8_t *)mask_dev,
-                           mask_frame_stride, mask_pitch, nframes, m->nframes,
-                           m->alpha_table, m->c);
+                           mask_frame_stride, mask_pitch, nframes,
+                           m.frames_before, m.alpha_table, *m.c);
         HK_LAUNCH_CHECK("mog_batch1_k");
     }
-    m->nframes += nframes;
+    return HK_OK;
+}
+
+static int apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
+                       long bgr_pitch, void *mask_dev, long mask_frame_stride,
+                       long mask_pitch, void *tiles_dev, int nframes,
+                       void *stream) {
+    if (!m || !bgr_dev || (!mask_dev && !tiles_dev))
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch: null argument");
+    hk::DeviceGuard guard(m->device);
+    const MogTarget t{m->width, m->height, m->n_pixels, m->planes,
+                      m->alpha_table, m->cost, m->order, m->n_groups,
+                      &m->frames_of_cost, m->nframes, &m->c};
+    const int rc = launch_batch(t, bgr_dev, bgr_frame_stride, bgr_pitch,
+                                mask_dev, mask_frame_stride, mask_pitch,
+                                tiles_dev, nframes, (hipStream_t)stream);
+    if (rc != HK_OK) return rc;
+    if (nframes > 0) m->nframes += nframes;
     return HK_OK;
 }
 

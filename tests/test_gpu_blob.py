@@ -40,19 +40,24 @@ def mask_smooth_noise(rng, h, w, size, thr):
     return (f > thr).astype(np.uint8) * 255
 
 
-def oracle_results(masks, params_height):
+def oracle_results(masks, params_height, by_color=True):
     from oracle import detect_ref as D
     p = D.hawkeye_params(params_height)
+    p.filterByColor = 1 if by_color else 0
     return ([D.find_blobs(m, p) for m in masks],
             [D.blob_detect(m, p) for m in masks])
 
 
-def check_against_oracle(masks, params_height=None):
+def check_against_oracle(masks, params_height=None, by_color=True):
+    """by_color=False: without the colour test hole contours are not dropped
+    (their centroid lies on background), so every traced hole shows."""
     from hawkeye_amd.detect import SimpleBlobDetector, hawkeye_blob_params
     t, h, w = masks.shape
     ph = h if params_height is None else params_height
-    want_c, want_k = oracle_results(masks, ph)
-    det = SimpleBlobDetector(w, h, params=hawkeye_blob_params(ph),
+    want_c, want_k = oracle_results(masks, ph, by_color)
+    params = hawkeye_blob_params(ph)
+    params.filterByColor = 1 if by_color else 0
+    det = SimpleBlobDetector(w, h, params=params,
                              max_frames=max(1, min(t, 16)))
     dev = torch.from_numpy(masks).cuda()
     got_c = []
@@ -133,6 +138,46 @@ def test_dense_noise_grows_the_work_lists():
         got = det.detect(torch.from_numpy(m[None]).cuda())[0]
         want = D.blob_detect(m, D.hawkeye_params(h))
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_holes_that_start_on_the_first_row_of_a_band():
+    """The border tracer works on bands of 64 rows out of an LDS window.  A
+    hole border steps up to row y0 - 1 on its first move and reads row y0 - 2
+    there: holes whose first pixel lies on rows 64 / 128 (first row of a
+    band), plain and as the lower part of a hole that starts further up (the
+    trace then climbs out of the band and must retire)."""
+    h, w = 200, 192
+    masks = np.zeros((4, h, w), np.uint8)
+    for f, y0 in enumerate((64, 128, 64, 128)):
+        m = masks[f]
+        for i, x0 in enumerate((10, 50, 90, 130)):
+            m[y0 - 4 - i:y0 + 14, x0:x0 + 24] = 255     # block
+            m[y0:y0 + 5 + i, x0 + 4:x0 + 10 + i] = 0     # hole, top row y0
+        if f >= 2:
+            # second arm of the hole of block 1, reaching 3 rows higher:
+            # the candidate at (x0 + 4, y0) is no longer the hole's first pixel
+            x0 = 50
+            m[y0 + 3, x0 + 4:x0 + 18] = 0
+            m[y0 - 3:y0 + 4, x0 + 17] = 0
+            # diagonal chain of holes across the band border (8-connected
+            # foreground between them)
+            x0 = 130
+            for k in range(5):
+                m[y0 - 3 + k, x0 + 14 + k] = 0
+        # a ring whose hole starts exactly one row above the band
+        yy, xx = np.mgrid[0:h, 0:w]
+        r2 = (xx - 170)**2 + (yy - (y0 + 5))**2
+        m[(r2 <= 81) & (r2 >= 30)] = 255
+    # (the parameter block of scan heights >= 480: areas up to 1000)
+    n_c, n_k = check_against_oracle(masks, params_height=480)
+    assert n_c >= 8
+    n_all, _ = check_against_oracle(masks, params_height=480, by_color=False)
+    assert n_all >= n_c + 12            # the holes are contours of their own
+    # the same picture shifted by one and two rows: starts on the last rows of
+    # the band above
+    for shift in (1, 2, 63):
+        check_against_oracle(np.roll(masks, -shift, axis=1),
+                             params_height=480, by_color=False)
 
 
 def test_full_hd_sparse_blobs():

@@ -54,7 +54,10 @@ def test_warmup_overlap_mask_and_event_agreement():
             matched += int((d.min(axis=1) <= 0.5).sum())
     print('segment-2 events matched within 0.5 px: {}/{} = {:.4f}'.format(
         matched, total, matched / max(1, total)))
-    assert matched >= 0.9 * total
+    # measured on MI355X: 0.974 (the rest are partial detections of slow
+    # distractor blobs whose MOG history the cold start lacks); pinned just
+    # below, so that a regression of the warm-up shows
+    assert matched >= 0.965 * total
 
 
 def test_scan_time_segmented_world1_equals_videoscanner(tmp_path):

@@ -82,6 +82,35 @@ def test_em_operations_match_reference_unit_vectors(golden_dir):
         assert [clip.eval_arc(k, False), clip.eval_arc(k, True)] == codes
 
 
+def test_m_step_skip_paths_match_the_reference(golden_dir):
+    """K6 arc_moments_k through hk_clip_set_arcs + hk_clip_fit_arcs on the
+    reference's own fit_arcs() results (tests/golden/make_golden_fit1.py, unit
+    weights): the fits, and every way the reference leaves an arc untouched
+    (reference tracker.py:714-715 fewer than 3 tags, :757-760 singular normal
+    equations, :786-788 NaN or e == 0)."""
+    from hawkeye_amd.arcs import Clip
+    with open(os.path.join(golden_dir, 'fit_unit_vectors.json')) as fh:
+        cases = json.load(fh)['fit_arcs_unit_weights']
+    assert sum(c['skipped'] for c in cases) >= 5
+    for case in cases:
+        tags = case['tags']
+        clip = Clip(1280, 720, 30.0, 200, [t[0] for t in tags],
+                    [t[1] for t in tags], [t[2] for t in tags],
+                    [16.0] * len(tags))
+        clip.set_state(camera_tilt=case['tilt'])
+        clip.set_arcs([case['start']], [list(range(len(tags)))])
+        clip.fit_arcs()
+        params, _, members = clip.arcs()
+        assert len(members[0]) == len(tags)
+        got = [float(v) for v in params[0]]
+        if case['skipped']:
+            assert got == case['start'] == case['result'], case['name']
+        else:
+            for g, w in zip(got, case['result']):
+                assert close(g, w), (case['name'], g, w)
+        clip.close()
+
+
 @pytest.mark.parametrize('name', RUNS)
 def test_em_optimize_matches_reference(golden_dir, name):
     with open(os.path.join(golden_dir, 'run_{}.json'.format(name))) as fh:

@@ -74,6 +74,29 @@ def test_fit_arcs(unit):
             assert close(got, want), (got, want)
 
 
+def test_fit_arcs_unit_weights_and_skip_paths(golden_dir):
+    """The reference's fit_arcs() with unit weights, including every way it
+    leaves an arc untouched (fit_unit_vectors.json)."""
+    cases = load(golden_dir, 'fit_unit_vectors.json')['fit_arcs_unit_weights']
+    assert sum(c['skipped'] for c in cases) >= 5
+    for case in cases:
+        sc = em_ref.Scene({}, 1280, 720, 30.0, frame_count=200)
+        sc.tilt = case['tilt']
+        tags = case['tags']
+        sc.frame = [t[0] for t in tags]
+        sc.x = [t[1] for t in tags]
+        sc.y = [t[2] for t in tags]
+        arc = em_ref.Arc()
+        arc.a, arc.b, arc.c, arc.e, arc.f_peak = case['start']
+        arc.tags = list(range(len(tags)))
+        sc.fit(arc, lambda i: 1.0)
+        if case['skipped']:
+            assert list(arc.params()) == case['start'], case['name']
+        else:
+            for got, want in zip(arc.params(), case['result']):
+                assert close(got, want), (case['name'], got, want)
+
+
 def test_estep_tilt_eval(unit):
     u = unit['estep']
     sc = em_ref.Scene(meas_of(u['meas']), u['width'], u['height'], u['fps'],
