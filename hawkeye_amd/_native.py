@@ -71,6 +71,11 @@ _sig('hk_mog_tiles_supported', [C.c_void_p])
 _sig('hk_mog_apply_batch_tiles', [C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                                   C.c_void_p, C.c_int, C.c_void_p])
 _sig('hk_mog_export_model', [C.c_void_p, C.c_void_p, C.c_void_p])
+_sig('hk_mog_apply_batch_static', [C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_long, C.c_long,
+                                   C.c_void_p, C.c_long, C.c_long, C.c_int,
+                                   C.c_void_p])
+
 
 class BlobParams(C.Structure):
     """hk_blob_params (include/hk.h); field names follow

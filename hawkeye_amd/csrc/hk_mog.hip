@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "hk_common.h"
@@ -946,6 +947,135 @@ extern "C" int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
                         "aligned");
     return apply_batch(m, bgr_dev, bgr_frame_stride, bgr_pitch, nullptr, 0, 0,
                        tiles_dev, nframes, stream);
+}
+
+// ---------------------------------------------------------------------------
+// hk_mog_apply_batch_static: the batch launch for callers that cannot call
+// hipMalloc (code under HIP graph capture, tight serving loops, harnesses that
+// forbid it).  The caller owns the model; everything else the launch needs
+// beyond inputs and outputs -- the alpha table and the launch-order
+// bookkeeping cost[] / order[] -- lives in `scratch`, a static device array
+// of this code object.  Every GPU the library runs on holds its own copy of
+// the array at its own address until the process ends.
+//
+// In host code the array's NAME is only a stand-in (passing it to a kernel
+// would compile and then fault on the GPU): its device address is looked up
+// once per device with hipGetSymbolAddress and only that pointer is used.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr long STATIC_MAX_PIXELS = 3840L * 2160L;       // one 4K frame
+constexpr int STATIC_MAX_GROUPS = (int)((STATIC_MAX_PIXELS / 2 + 255) / 256);
+constexpr size_t STATIC_ALPHA_BYTES = 1024;             // HISTORY floats, padded
+constexpr size_t STATIC_SCRATCH_BYTES =
+    STATIC_ALPHA_BYTES + 2 * sizeof(int) * (size_t)STATIC_MAX_GROUPS;   // 128 KB
+static_assert(sizeof(float) * HISTORY <= STATIC_ALPHA_BYTES, "alpha table");
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+namespace {
+
+// alpha[i] = (float)(1. / (i + 1)), as hk_mog_create computes it on the host
+// (IEEE double division, then one rounding to float).
+__global__ __launch_bounds__(256) void mog_alpha_table_k(float *alpha) {
+    const int i = threadIdx.x;
+    if (i < HISTORY) alpha[i] = (float)(1. / (double)(i + 1));
+}
+
+constexpr int STATIC_MAX_DEVICES = 64;
+
+struct StaticState {            // per device, guarded by static_mutex
+    unsigned char *ptr = nullptr;       // device address of `scratch` there
+    const void *model = nullptr;        // model of the call that wrote cost[]
+    int n_groups = 0;
+    int frames_of_cost = 0;
+    int frames_after = 0;       // frames the model had seen after that call
+};
+StaticState static_state[STATIC_MAX_DEVICES];
+std::mutex static_mutex;
+
+}  // namespace
+
+extern "C" int hk_mog_apply_batch_static(
+    int width, int height, int device, void *model_dev, int frames_before,
+    const void *bgr_dev, long bgr_frame_stride, long bgr_pitch, void *mask_dev,
+    long mask_frame_stride, long mask_pitch, int nframes, void *stream) {
+    if (width <= 0 || height <= 0)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch_static: bad size %dx%d",
+                        width, height);
+    if (!model_dev || !bgr_dev || !mask_dev)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch_static: null argument");
+    if (frames_before < 0)
+        return hk::fail(HK_ERR_ARG,
+                        "hk_mog_apply_batch_static: frames_before %d",
+                        frames_before);
+    if ((uintptr_t)model_dev & 7)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch_static: model must be "
+                                    "8-byte aligned");
+    if (device < 0 || device >= STATIC_MAX_DEVICES)
+        return hk::fail(HK_ERR_ARG, "hk_mog_apply_batch_static: device %d "
+                                    "outside 0..%d", device,
+                        STATIC_MAX_DEVICES - 1);
+    const long N = (long)width * height;
+    if (N > STATIC_MAX_PIXELS)
+        return hk::fail(HK_ERR_CAPACITY,
+                        "hk_mog_apply_batch_static: %dx%d = %ld pixels exceed "
+                        "the static scratch buffer's maximum of %ld (3840x2160); "
+                        "use hk_mog_create + hk_mog_apply_batch", width, height,
+                        N, STATIC_MAX_PIXELS);
+    hk::DeviceGuard guard(device);
+    if (!guard.ok)
+        return hk::fail(HK_ERR_HIP, "hk_mog_apply_batch_static: cannot select "
+                                    "device %d", device);
+    std::lock_guard<std::mutex> lock(static_mutex);
+    StaticState &st = static_state[device];
+    if (!st.ptr) {              // once per device, with that device current
+        void *p = nullptr;
+        HK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+            return hk::fail(HK_ERR_HIP, "hk_mog_apply_batch_static: no device "
+                                        "address for the scratch array");
+        st.ptr = (unsigned char *)p;
+    }
+    const hipStream_t s = (hipStream_t)stream;
+    float *const alpha = (float *)st.ptr;
+    int *const cost = (int *)(st.ptr + STATIC_ALPHA_BYTES);
+    int *const order = cost + STATIC_MAX_GROUPS;
+    const int n_groups = (int)((N / 2 + 255) / 256);
+
+    // The array keeps the last call's contents.  The alpha table is the same
+    // for every call but is rewritten on this call's stream, so that a call
+    // never reads what a call on another stream may still be writing.  cost[]
+    // is reused (to order this launch, slowest groups first) only if the last
+    // call that wrote it worked on the same model, the same geometry and the
+    // frames right before these; otherwise it starts at zero.
+    hipLaunchKernelGGL(mog_alpha_table_k, dim3(1), dim3(256), 0, s, alpha);
+    HK_LAUNCH_CHECK("mog_alpha_table_k");
+    static const MogConst consts = opencv_defaults();
+    int frames_of_cost = 0;
+    if (nframes > 4) {
+        const bool continues = st.model == model_dev &&
+                               st.n_groups == n_groups &&
+                               st.frames_of_cost > 0 && frames_before > 0 &&
+                               st.frames_after == frames_before;
+        if (continues) frames_of_cost = st.frames_of_cost;
+        else HK_HIP(hipMemsetAsync(cost, 0, sizeof(int) * n_groups, s));
+    }
+    const MogTarget t{width, height, N, (float *)model_dev, alpha, cost, order,
+                      n_groups, &frames_of_cost, frames_before, &consts};
+    const int rc = launch_batch(t, bgr_dev, bgr_frame_stride, bgr_pitch,
+                                mask_dev, mask_frame_stride, mask_pitch,
+                                nullptr, nframes, s);
+    if (rc != HK_OK) return rc;
+    if (nframes > 4) {
+        st.model = model_dev;
+        st.n_groups = n_groups;
+        st.frames_of_cost = frames_of_cost;     // = nframes (fast path) or 0
+        st.frames_after = frames_before + nframes;
+    }
+    return HK_OK;
 }
 
 extern "C" int hk_mog_apply(hk_mog *m, const void *bgr_dev, long bgr_pitch,

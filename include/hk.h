@@ -98,6 +98,36 @@ int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
                              long bgr_frame_stride, long bgr_pitch,
                              void *tiles_dev, int nframes, void *stream);
 
+/* hk_mog_apply_batch for callers that cannot allocate device memory.  It has
+ * NO counterpart in the reference; it exists for callers that cannot call
+ * hipMalloc at all: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  It calls no hipMalloc / hipFree or any
+ * other allocating routine.
+ *
+ * The caller owns the model: model_dev = float [40][width*height] on `device`
+ * (plane = field*5 + k, fields weight, sortKey, mean[3], var[3]; all zero for
+ * a fresh model), updated in place; frames_before = frames that model has
+ * seen (0 for a fresh one).  The other arguments are hk_mog_apply_batch's.
+ * What that entry point keeps in buffers of its handle besides the model --
+ * the learning-rate table and the per-group cost / launch order lists of the
+ * batch kernel -- lives here in a static device array of the library
+ * (128 KB; each GPU the library runs on holds it until the process ends),
+ * which limits frames to 3840x2160 pixels: larger ones are rejected with
+ * HK_ERR_CAPACITY.  Results are identical to hk_mog_apply_batch (the launch
+ * order is scheduling only).
+ * Every call on a GPU shares that GPU's array, which keeps the previous
+ * call's contents: the call re-initialises what it reads, but calls that
+ * OVERLAP on one GPU (two host threads, or two streams with both launches in
+ * flight) race on it.  The first call on a device looks the array's device
+ * address up (hipGetSymbolAddress); make that call outside stream capture.
+ * Enqueues on `stream`. */
+int hk_mog_apply_batch_static(int width, int height, int device,
+                              void *model_dev, int frames_before,
+                              const void *bgr_dev, long bgr_frame_stride,
+                              long bgr_pitch, void *mask_dev,
+                              long mask_frame_stride, long mask_pitch,
+                              int nframes, void *stream);
+
 /* Copies the model to host in OpenCV's AoS order: float [H*W][5][8] =
  * (sortKey, weight, mean[3], var[3]).  For tests.  Synchronises. */
 int hk_mog_export_model(hk_mog *m, float *host_out, void *stream);
