@@ -272,53 +272,58 @@ __device__ __forceinline__ f2 div_ranged2(f2 n, f2 d) {
 // sortKey of component 0, deferred.  A fast step would set
 //     SK[0] = (w_old / sqrt(var sum)) * wscale,
 // a value nothing reads if the next frame takes the fast step again (it is
-// overwritten from scratch).  So the fast step only notes the three operands;
-// the square root, the division and the product are done when the value is
+// overwritten from scratch).  So the fast step only notes the operands; the
+// square root, the division and the product are done when the value is
 // needed: before a general step of this lane, and before the model is stored.
+// The variance sum is the lane's carried `vsum` (see mog_step_pair0): it does
+// not change between the fast step and the moment the key is materialised.
 struct LazySK {
-    f2 w, s, scale;         // s == 0: SK[0] in the model is current
+    f2 w, scale;            // w.x == 0: SK[0] in the model is current (the
+                            // two pixels of a lane take the fast step
+                            // together, and a weight that does is > 0)
 };
 
-__device__ __forceinline__ void materialise_sk0(Mix2 &p, LazySK &z) {
-    const bool sx = z.s.x != 0.f, sy = z.s.y != 0.f;
-    f2 s;
-    s.x = sx ? z.s.x : 1024.f;
-    s.y = sy ? z.s.y : 1024.f;
-    f2 w;
-    w.x = sx ? z.w.x : 1.f;
-    w.y = sy ? z.w.y : 1.f;
+__device__ __forceinline__ void materialise_sk0(Mix2 &p, LazySK &z, f2 vsum) {
+    const bool pend = z.w.x != 0.f;
+    f2 s, w;
+    s.x = pend ? vsum.x : 1024.f;
+    s.y = pend ? vsum.y : 1024.f;
+    w.x = pend ? z.w.x : 1.f;
+    w.y = pend ? z.w.y : 1.f;
     const f2 sk = div_ranged2(w, sqrt_ranged2(s)) * z.scale;
-    p.f[F_SK][0].x = sx ? sk.x : p.f[F_SK][0].x;
-    p.f[F_SK][0].y = sy ? sk.y : p.f[F_SK][0].y;
-    z.s.x = 0.f;
-    z.s.y = 0.f;
+    p.f[F_SK][0].x = pend ? sk.x : p.f[F_SK][0].x;
+    p.f[F_SK][0].y = pend ? sk.y : p.f[F_SK][0].y;
+    z.w.x = 0.f;
 }
 
-// Both pixels of `p` against their component 0.  Returns true and the 16-bit
-// mask pair if both matched (model updated, SK[0] deferred into `z`); false
-// with `p` untouched if either did not.
-__device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
-                                               f2 x1, f2 x2, float alpha,
-                                               const MogConst c,
-                                               unsigned &mask) {
-    const f2 w = p.f[F_W][0];
-    const f2 d0 = x0 - p.f[F_M0][0];
-    const f2 d1 = x1 - p.f[F_M1][0];
-    const f2 d2 = x2 - p.f[F_M2][0];
-    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
-    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-    f2 dist2 = q0 + q1;
-    dist2 = dist2 + q2;
-    const f2 thr = c.vT * ((v0 + v1) + v2);
-    const bool hit = !(w.x < FLT_EPSILON) && !(w.y < FLT_EPSILON) &&
-                     dist2.x < thr.x && dist2.y < thr.y;
-    if (!hit) return false;
+// OpenCV's constants as literals for the fast step (a kernel argument is not
+// known to be free of NaNs, which costs a canonicalising instruction per use);
+// hk_mog_create checks that opencv_defaults() yields exactly these.
+constexpr float FAST_T = 0.7f, FAST_VT = 6.25f, FAST_MINVAR = 225.f;
 
+// The update of a fast step in a wave whose lanes hold at most nc components
+// (wave-uniform; 1, 2 or K).  A component that was never created has weight 0
+// and sort key 0: adding the one to a positive sum and scaling either changes
+// nothing, so those operations are skipped -- same results, and most waves
+// only hold pixels with one mode.  Returns the cumulated weights.
+__device__ __forceinline__ f2 fast_update(Mix2 &p, LazySK &z, f2 &vsum, int nc,
+                                          f2 w, f2 d0, f2 d1, f2 d2, f2 q0,
+                                          f2 q1, f2 q2, float alpha) {
+    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
     const f2 one = {1.f, 1.f};
     const f2 wn = w + alpha * (one - w);
-    f2 wsum = wn + p.f[F_W][1];
+    // (the empty asm statements keep these wave-uniform branches branches:
+    // turned into selects they would cost more than they skip)
+    f2 wsum = wn;
+    if (nc >= 2) {
+        asm volatile("; two components");
+        wsum = wsum + p.f[F_W][1];
+        if (nc > 2) {
+            asm volatile("; up to five components");
 #pragma unroll
-    for (int k = 2; k < K; ++k) wsum = wsum + p.f[F_W][k];
+            for (int k = 2; k < K; ++k) wsum = wsum + p.f[F_W][k];
+        }
+    }
     // 1 / wsum: its dependent fma chain is interleaved by hand with the
     // independent mean / variance updates (same operations, same operands)
     f2 r0;
@@ -336,28 +341,102 @@ __device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
     const f2 e2 = fma2(-wsum, q1r, one);
     v2 = v2 + alpha * (q2 - v2);
     const f2 wscale = fma2(e2, r, q1r);
-    v0.x = __builtin_fmaxf(v0.x, c.minVar);
-    v0.y = __builtin_fmaxf(v0.y, c.minVar);
-    v1.x = __builtin_fmaxf(v1.x, c.minVar);
-    v1.y = __builtin_fmaxf(v1.y, c.minVar);
-    v2.x = __builtin_fmaxf(v2.x, c.minVar);
-    v2.y = __builtin_fmaxf(v2.y, c.minVar);
+    v0.x = __builtin_fmaxf(v0.x, FAST_MINVAR);
+    v0.y = __builtin_fmaxf(v0.y, FAST_MINVAR);
+    v1.x = __builtin_fmaxf(v1.x, FAST_MINVAR);
+    v1.y = __builtin_fmaxf(v1.y, FAST_MINVAR);
+    v2.x = __builtin_fmaxf(v2.x, FAST_MINVAR);
+    v2.y = __builtin_fmaxf(v2.y, FAST_MINVAR);
     p.f[F_V0][0] = v0;
     p.f[F_V1][0] = v1;
     p.f[F_V2][0] = v2;
     z.w = w;
-    z.s = (v0 + v1) + v2;
     z.scale = wscale;
+    vsum = (v0 + v1) + v2;
 
     p.f[F_W][0] = wn * wscale;
     f2 cum = p.f[F_W][0];
+    if (nc >= 2) {
+        asm volatile("; two components");
+        p.f[F_W][1] = p.f[F_W][1] * wscale;
+        cum = cum + p.f[F_W][1];
+        p.f[F_SK][1] = p.f[F_SK][1] * wscale;
+        if (nc > 2) {
+            asm volatile("; up to five components");
 #pragma unroll
-    for (int k = 1; k < K; ++k) {
-        p.f[F_W][k] = p.f[F_W][k] * wscale;
-        cum = cum + p.f[F_W][k];
-        p.f[F_SK][k] = p.f[F_SK][k] * wscale;
+            for (int k = 2; k < K; ++k) {
+                p.f[F_W][k] = p.f[F_W][k] * wscale;
+                cum = cum + p.f[F_W][k];
+                p.f[F_SK][k] = p.f[F_SK][k] * wscale;
+            }
+        }
     }
-    mask = (cum.x > c.T ? 0u : 255u) | (cum.y > c.T ? 0u : 255u << 8);
+    return cum;
+}
+
+// The update of a fast step in a wave in which every pixel has one component
+// and that component's weight is exactly 1 (a pixel that has only ever seen
+// its background: the steady state of most of the picture).  Then
+//     wn = 1 + alpha * (1 - 1) = 1,  wsum = 1,  wscale = 1 / 1 = 1,
+//     W[0] = wn * wscale = 1,        cum = 1 > T: background,
+// all exactly, so the weight arithmetic of fast_update is skipped whole and
+// only the mean and the variance move.
+__device__ __forceinline__ void unit_update(Mix2 &p, LazySK &z, f2 &vsum, f2 d0,
+                                            f2 d1, f2 d2, f2 q0, f2 q1, f2 q2,
+                                            float alpha) {
+    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
+    p.f[F_M0][0] = p.f[F_M0][0] + alpha * d0;
+    p.f[F_M1][0] = p.f[F_M1][0] + alpha * d1;
+    p.f[F_M2][0] = p.f[F_M2][0] + alpha * d2;
+    v0 = v0 + alpha * (q0 - v0);
+    v1 = v1 + alpha * (q1 - v1);
+    v2 = v2 + alpha * (q2 - v2);
+    v0.x = __builtin_fmaxf(v0.x, FAST_MINVAR);
+    v0.y = __builtin_fmaxf(v0.y, FAST_MINVAR);
+    v1.x = __builtin_fmaxf(v1.x, FAST_MINVAR);
+    v1.y = __builtin_fmaxf(v1.y, FAST_MINVAR);
+    v2.x = __builtin_fmaxf(v2.x, FAST_MINVAR);
+    v2.y = __builtin_fmaxf(v2.y, FAST_MINVAR);
+    p.f[F_V0][0] = v0;
+    p.f[F_V1][0] = v1;
+    p.f[F_V2][0] = v2;
+    z.w = f2{1.f, 1.f};
+    z.scale = f2{1.f, 1.f};
+    vsum = (v0 + v1) + v2;
+}
+
+// Both pixels of `p` against their component 0.  Returns true if both
+// matched: model updated, SK[0] deferred into `z`, cum = the cumulated
+// weights of the two pixels (kHit == 0: a pixel is foreground iff its weights
+// never sum past T).  False with `p` and `cum` untouched if either did not.
+// nc (wave-uniform): no lane of the wave holds more than nc components;
+// unit (wave-uniform): nc == 1 and every weight W[0] is exactly 1.
+// vsum: (var0 + var1) + var2 of component 0, carried from frame to frame (the
+// value the threshold needs is the one the previous step's update ended
+// with); recomputed by the caller after a general step.
+__device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 &vsum,
+                                               int nc, bool unit, f2 x0, f2 x1,
+                                               f2 x2, float alpha, f2 &cum) {
+    const f2 w = p.f[F_W][0];
+    const f2 d0 = x0 - p.f[F_M0][0];
+    const f2 d1 = x1 - p.f[F_M1][0];
+    const f2 d2 = x2 - p.f[F_M2][0];
+    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    f2 dist2 = q0 + q1;
+    dist2 = dist2 + q2;
+    const f2 thr = FAST_VT * vsum;
+    // weights are never negative: their bit patterns order like the values
+    const unsigned wmin = min(__float_as_uint(w.x), __float_as_uint(w.y));
+    const bool hit = wmin >= __float_as_uint(FLT_EPSILON) &&
+                     dist2.x < thr.x && dist2.y < thr.y;
+    if (!hit) return false;
+    if (unit) {
+        asm volatile("; unit weights");
+        unit_update(p, z, vsum, d0, d1, d2, q0, q1, q2, alpha);
+        cum = f2{1.f, 1.f};
+    } else {
+        cum = fast_update(p, z, vsum, nc, w, d0, d1, d2, q0, q1, q2, alpha);
+    }
     return true;
 }
 
@@ -378,7 +457,38 @@ __device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 x0,
 // 128 VGPRs: the rarely used half of the model sits in LDS, DEPTH frames of
 // input are requested ahead (every frame's bytes are an HBM miss).
 // ---------------------------------------------------------------------------
-template <int WAVES, int DEPTH, bool TILED>
+// acc with lanes first .. first + 3 set to the (wave-uniform) words w0 .. w3:
+// four v_writelane_b32 with the lane number in M0 (a VOP3 takes one SGPR
+// operand only, and `first` is not a compile-time constant).  M0 is saved and
+// restored inside the statement.
+__device__ __forceinline__ unsigned write_4_lanes(unsigned acc, int first,
+                                                  unsigned w0, unsigned w1,
+                                                  unsigned w2, unsigned w3) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %1, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %0, %2, m0\n\t"
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %0, %3, m0\n\t"
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %0, %4, m0\n\t"
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %0, %5, m0\n\t"
+        "s_mov_b32 m0, %1"
+        : "+v"(acc), "=&s"(keep)
+        : "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(first)
+        : "scc");
+    return acc;
+}
+
+// MASKS: byte masks are written (hk_mog_apply_batch); TILES: the 1-bit tile
+// words are (hk_mog_apply_batch_tiles, TILED geometry only).
+template <int WAVES, int DEPTH, bool TILED, bool MASKS, bool TILES>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     float *__restrict__ planes, long n_pixels, int width,
@@ -388,6 +498,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     const MogConst c, int n_groups, const int *__restrict__ order,
     int *__restrict__ cost, unsigned *__restrict__ tiles,
     long tile_words_per_frame) {
+    static_assert(!TILES || TILED, "tile words need the tiled geometry");
     // One wave per workgroup, so that a finished wave's slot and LDS are
     // reused at once (waves of one workgroup end at very different times).
     // A "group" is 4 units of 128 pixels that share cache lines of the frame
@@ -402,22 +513,27 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     const long g = ((long)group * 4 + (j & 3)) * 64 + threadIdx.x;  // pair
     long i0 = g * 2;
     if (i0 >= n_pixels) return;
+    const int lane = threadIdx.x;
     if (TILED) {
         // A wave owns a 32 x 4 pixel tile instead of a 128-pixel run of a
         // row: pixels off the fast path come in compact 2-D groups (moving
         // objects, their edges), which then touch ~3x fewer waves.
         // Requires width % 32 == 0 and height % 4 == 0.
-        const int lane = threadIdx.x;
         const long tile = g >> 6;
         const int tiles_x = width >> 5;
         const long ty = tile / tiles_x;
         const int tx = (int)(tile - ty * tiles_x);
         i0 = (ty * 4 + (lane >> 4)) * width + tx * 32 + (lane & 15) * 2;
     }
-    // TILED only: where this wave's tile goes in the 1-bit output (4 words
-    // per tile and frame, see hk_mog_apply_batch_tiles), lanes 0-3 a word each
+    // TILES: the wave's tile takes 4 words per frame in the 1-bit output (see
+    // hk_mog_apply_batch_tiles).  The words of 16 frames are collected in one
+    // register, lane L = word L & 3 of frame L >> 2 of the group of 16, and
+    // stored together.
     unsigned *tile_dst = nullptr;
-    if (TILED && tiles) tile_dst = tiles + (g >> 6) * 4 + (threadIdx.x & 3);
+    unsigned tile_acc = 0u;
+    if (TILES)
+        tile_dst = tiles + (g >> 6) * 4 + (lane & 3) +
+                   (long)(lane >> 2) * tile_words_per_frame;
 
     // A component that was never created has weight 0 and all-zero fields
     // (the model starts zeroed, components are created with weight w0 > 0 and
@@ -455,8 +571,27 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     }
 
     LazySK lazy;
-    lazy.w = lazy.s = lazy.scale = f2{0.f, 0.f};
+    lazy.w = lazy.scale = f2{0.f, 0.f};
     int slow_steps = 0;     // frames in which this wave left the fast step
+    // variance sum of component 0 (the fast step's threshold operand) and
+    // the largest number of components any lane of the wave holds (1, 2 or
+    // "up to 5"): both change only in the general step
+    f2 vsum = (px.f[F_V0][0] + px.f[F_V1][0]) + px.f[F_V2][0];
+    auto count_components = [&]() {
+        const bool two = px.f[F_W][1].x != 0.f || px.f[F_W][1].y != 0.f;
+        const bool more = px.f[F_W][2].x != 0.f || px.f[F_W][2].y != 0.f;
+        return __builtin_amdgcn_ballot_w64(more) ? K
+               : __builtin_amdgcn_ballot_w64(two) ? 2 : 1;
+    };
+    int nc = count_components();
+    // nc == 1 and every W[0] == 1 (see unit_update); while a wave with single
+    // components is not there yet it is looked at again after every frame
+    auto unit_weights = [&]() {
+        return nc == 1 &&
+               __builtin_amdgcn_ballot_w64(px.f[F_W][0].x != 1.f ||
+                                           px.f[F_W][0].y != 1.f) == 0;
+    };
+    bool unit = unit_weights();
 
     // The 6 input bytes of a frame are far from those of the next frame, so
     // every load is an HBM miss (~2 us under load): the frames of the next
@@ -499,37 +634,63 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                 x0.y = (float)(c01 >> 24);
                 x1.y = (float)(c2 & 255u);
                 x2.y = (float)(c2 >> 8);
-                unsigned m;
-                const bool fast = mog_step_pair0(px, lazy, x0, x1, x2, alpha,
-                                                 c, m);
-                slow_steps += __builtin_amdgcn_ballot_w64(!fast) != 0;
+                // cum: > T = background.  The fast step leaves each
+                // pixel's cumulated weights there, the general step a
+                // stand-in on the right side of T, so that one compare per
+                // pixel after the two paths have joined yields the wave's
+                // foreground bits (a boolean merged across the paths would
+                // cost two more vector instructions each)
+                f2 cum;
+                const bool fast = mog_step_pair0(px, lazy, vsum, nc, unit, x0,
+                                                 x1, x2, alpha, cum);
+                const bool any_slow = __builtin_amdgcn_ballot_w64(!fast) != 0;
                 if (!fast) {
                     // the launch ends when its slowest wave does: waves in
                     // the long general step go first at instruction issue
                     __builtin_amdgcn_s_setprio(3);
-                    materialise_sk0(px, lazy);
+                    materialise_sk0(px, lazy, vsum);
                     Lane<0> l0{px};
                     Lane<1> l1{px};
-                    m = mog_step(l0, x0.x, x1.x, x2.x, alpha, c);
-                    m |= mog_step(l1, x0.y, x1.y, x2.y, alpha, c) << 8;
+                    cum.x = mog_step(l0, x0.x, x1.x, x2.x, alpha, c) ? 0.f
+                                                                      : 1.f;
+                    cum.y = mog_step(l1, x0.y, x1.y, x2.y, alpha, c) ? 0.f
+                                                                      : 1.f;
+                    vsum = (px.f[F_V0][0] + px.f[F_V1][0]) + px.f[F_V2][0];
                     __builtin_amdgcn_s_setprio(0);
                 }
-                if (mask)
+                const bool f0 = !(cum.x > FAST_T), f1 = !(cum.y > FAST_T);
+                if (any_slow) {
+                    ++slow_steps;
+                    nc = count_components();
+                    unit = false;
+                }
+                if (!unit) unit = unit_weights();
+                if (MASKS) {
+                    const unsigned m = (f0 ? 255u : 0u) | (f1 ? 255u << 8 : 0u);
                     *reinterpret_cast<unsigned short *>(
                         dst + (long)t * mask_frame_stride) = (unsigned short)m;
-                if (TILED && tiles) {
-                    // foreground bits of the even and of the odd pixels of
-                    // the tile, a lane (= pixel pair) per bit
-                    const unsigned long long b0 =
-                        __builtin_amdgcn_ballot_w64((m & 1u) != 0u);
-                    const unsigned long long b1 =
-                        __builtin_amdgcn_ballot_w64((m & 0x100u) != 0u);
-                    if (threadIdx.x < 4) {
-                        const unsigned long long b = threadIdx.x & 2 ? b1 : b0;
-                        tile_dst[(long)t * tile_words_per_frame] =
-                            threadIdx.x & 1 ? (unsigned)(b >> 32) : (unsigned)b;
-                    }
                 }
+                if (TILES) {
+                    const unsigned long long fg0 =
+                        __builtin_amdgcn_ballot_w64(f0);
+                    const unsigned long long fg1 =
+                        __builtin_amdgcn_ballot_w64(f1);
+                    tile_acc = write_4_lanes(tile_acc, (t & 15) * 4,
+                                             (unsigned)fg0,
+                                             (unsigned)(fg0 >> 32),
+                                             (unsigned)fg1,
+                                             (unsigned)(fg1 >> 32));
+                }
+            }
+        }
+        if (TILES) {
+            // frames [first, t0 + DEPTH) of the current group of 16 are in
+            // tile_acc; store when the group is complete or the batch ends
+            const int done = t0 + DEPTH < nframes ? t0 + DEPTH : nframes;
+            if ((done & 15) == 0 || done == nframes) {
+                const int first = (done - 1) & ~15;
+                if (first + (lane >> 2) < done)
+                    tile_dst[(long)first * tile_words_per_frame] = tile_acc;
             }
         }
 #pragma unroll
@@ -541,7 +702,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 
     if (cost && threadIdx.x == 0 && slow_steps)
         atomicMax(&cost[group], slow_steps);
-    materialise_sk0(px, lazy);
+    materialise_sk0(px, lazy, vsum);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         *reinterpret_cast<float2 *>(base + (long)(F_W * K + k) * n_pixels) =
@@ -745,6 +906,10 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
     m->device = device;
     m->n_pixels = (long)width * height;
     m->c = opencv_defaults();
+    if (m->c.T != FAST_T || m->c.vT != FAST_VT || m->c.minVar != FAST_MINVAR) {
+        delete m;
+        return hk::fail(HK_ERR_INTERNAL, "hk_mog_create: constants");
+    }
 
     const size_t bytes = sizeof(float) * NPLANES * (size_t)m->n_pixels;
     hipError_t e = hipMalloc((void **)&m->planes, bytes);
@@ -849,9 +1014,9 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
         // short launches stream the model (HBM-bound), long ones are
         // bound by the latency of the frame loads and by arithmetic: see
         // mog_batch2_k
-#define HK_MOG_LAUNCH(W, D, TL)                                               \
-        hipLaunchKernelGGL((mog_batch2_k<W, D, TL>), dim3(blocks), dim3(64),  \
-                           0, s, m.planes, N, m.width,                        \
+#define HK_MOG_LAUNCH(W, D, TL, MK, TS)                                       \
+        hipLaunchKernelGGL((mog_batch2_k<W, D, TL, MK, TS>), dim3(blocks),    \
+                           dim3(64), 0, s, m.planes, N, m.width,              \
                            (const uint8_t *)bgr_dev,                          \
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
                            mask_frame_stride, nframes, m.frames_before,       \
@@ -879,11 +1044,13 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
             *m.frames_of_cost = nframes;
         }
         if (nframes <= 4) {
-            if (tileable) HK_MOG_LAUNCH(4, 1, true);
-            else HK_MOG_LAUNCH(4, 1, false);
+            if (tiles_dev) HK_MOG_LAUNCH(4, 1, true, false, true);
+            else if (tileable) HK_MOG_LAUNCH(4, 1, true, true, false);
+            else HK_MOG_LAUNCH(4, 1, false, true, false);
         } else {
-            if (tileable) HK_MOG_LAUNCH(4, 4, true);
-            else HK_MOG_LAUNCH(4, 4, false);
+            if (tiles_dev) HK_MOG_LAUNCH(4, 4, true, false, true);
+            else if (tileable) HK_MOG_LAUNCH(4, 4, true, true, false);
+            else HK_MOG_LAUNCH(4, 4, false, true, false);
         }
 #undef HK_MOG_LAUNCH
         HK_LAUNCH_CHECK("mog_batch2_k");

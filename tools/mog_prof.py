@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--chunk', type=int, default=128)
     ap.add_argument('--config', default='C_1080p60_9ball_noisy')
+    ap.add_argument('--no-reset', action='store_true',
+                    help='the model carries on from repetition to repetition')
     args = ap.parse_args()
     spec = dict(synth.CLIPS[args.config])
     spec['frames'] = max(args.frames, 8)
@@ -47,7 +49,8 @@ def main():
     torch.cuda.synchronize()
     times = []
     for rep in range(args.reps):
-        mog.reset()
+        if not args.no_reset or rep == 0:
+            mog.reset()
         for s in range(0, args.frames - args.chunk + 1, args.chunk):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)

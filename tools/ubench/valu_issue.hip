@@ -136,6 +136,39 @@ __global__ __launch_bounds__(1024) void issue_k(unsigned long long *stamps,
 #define A(i) asm volatile("v_fma_f32 %0, %2, %3, %0\n\tv_fma_f32 %1, %2, %3, %1" : "+v"(s[i]), "+v"(r[i].x) : "v"(y), "v"(x.x));
             REP16(A) REP16(A)
 #undef A
+        } else if (KIND == 18) {    // s_add_u32 on rotating registers
+            unsigned q0 = 1, q1 = 2, q2 = 3, q3 = 4;
+#define A(i) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3) : : "scc");
+            REP16(A)
+#undef A
+            if (q0 + q1 + q2 + q3 == 0x7fffffffu) s[0] += 1.f;
+        } else if (KIND == 19) {    // s_nop 0
+#define A(i) asm volatile("s_nop 0");
+            REP64(A)
+#undef A
+        } else if (KIND == 20) {    // v_pk_fma_f32 + s_add_u32 (pair)
+            unsigned q0 = 1;
+#define A(i) asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n\ts_add_u32 %1, %1, 1" : "+v"(r[i]), "+s"(q0) : "v"(x), "v"(x) : "scc");
+            REP16(A) REP16(A)
+#undef A
+            if (q0 == 0x7fffffffu) s[0] += 1.f;
+        } else if (KIND == 21) {    // v_pk_fma_f32 + 2 x s_add_u32 (triple)
+            unsigned q0 = 1, q1 = 2;
+#define A(i) asm volatile("v_pk_fma_f32 %0, %3, %4, %0\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1" : "+v"(r[i]), "+s"(q0), "+s"(q1) : "v"(x), "v"(x) : "scc");
+            REP16(A) REP16(A)
+#undef A
+            if (q0 + q1 == 0x7fffffffu) s[0] += 1.f;
+        } else if (KIND == 22) {    // v_add_f32 + s_add_u32 (pair)
+            unsigned q0 = 1;
+#define A(i) asm volatile("v_add_f32 %0, %0, %2\n\ts_add_u32 %1, %1, 1" : "+v"(s[i]), "+s"(q0) : "v"(y) : "scc");
+            REP16(A) REP16(A)
+#undef A
+            if (q0 == 0x7fffffffu) s[0] += 1.f;
+        } else if (KIND == 23) {    // s_cmp + s_cbranch not taken
+            const unsigned us = __builtin_amdgcn_readfirstlane(u);
+#define A(i) asm volatile("s_cmp_eq_u32 %0, 0x12345\n\ts_cbranch_scc1 1f\n\t1:" : : "s"(us) : "scc");
+            REP16(A) REP16(A)
+#undef A
         } else if (KIND == 11) {    // v_pk_fma_f32 with an SGPR-pair operand
 #define A(i) asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(r[i]) : "s"(x));
             REP64(A)
@@ -224,5 +257,11 @@ int main() {
     run<15>("v_pk_fma_f32 + v_add_f32 (pair)", 32, d_stamps, d_sink);
     run<16>("v_pk_fma_f32 + v_max_f32 (pair)", 32, d_stamps, d_sink);
     run<17>("2 x v_fma_f32 (pair)", 32, d_stamps, d_sink);
+    run<18>("s_add_u32", 64, d_stamps, d_sink);
+    run<19>("s_nop 0", 64, d_stamps, d_sink);
+    run<20>("v_pk_fma_f32 + s_add_u32 (pair)", 32, d_stamps, d_sink);
+    run<21>("v_pk_fma_f32 + 2 s_add_u32 (triple)", 32, d_stamps, d_sink);
+    run<22>("v_add_f32 + s_add_u32 (pair)", 32, d_stamps, d_sink);
+    run<23>("s_cmp + s_cbranch not taken (pair)", 32, d_stamps, d_sink);
     return 0;
 }
