@@ -34,6 +34,9 @@ namespace {
 constexpr int K = 5;
 constexpr int NPLANES = 8 * K;
 constexpr int HISTORY = 200;
+// learning rates 1 / min(n, HISTORY) for n = 1 .., padded so that the batch
+// kernel can fetch the rates of a group of 4 frames from one clamped index
+constexpr int ALPHA_ENTRIES = HISTORY + 4;
 
 enum Field { F_W = 0, F_SK, F_M0, F_M1, F_M2, F_V0, F_V1, F_V2 };
 
@@ -275,8 +278,8 @@ __device__ __forceinline__ f2 div_ranged2(f2 n, f2 d) {
 // overwritten from scratch).  So the fast step only notes the operands; the
 // square root, the division and the product are done when the value is
 // needed: before a general step of this lane, and before the model is stored.
-// The variance sum is the lane's carried `vsum` (see mog_step_pair0): it does
-// not change between the fast step and the moment the key is materialised.
+// The variance sum is the lane's carried `vsum` (see the kernel): it does not
+// change between the fast step and the moment the key is materialised.
 struct LazySK {
     f2 w, scale;            // w.x == 0: SK[0] in the model is current (the
                             // two pixels of a lane take the fast step
@@ -301,14 +304,65 @@ __device__ __forceinline__ void materialise_sk0(Mix2 &p, LazySK &z, f2 vsum) {
 // hk_mog_create checks that opencv_defaults() yields exactly these.
 constexpr float FAST_T = 0.7f, FAST_VT = 6.25f, FAST_MINVAR = 225.f;
 
-// The update of a fast step in a wave whose lanes hold at most nc components
+// Both pixels of a lane against their component 0: differences, their
+// squares and the squared distance.
+struct Probe {
+    f2 d0, d1, d2, q0, q1, q2, dist2;
+};
+
+__device__ __forceinline__ Probe probe0(const Mix2 &p, f2 x0, f2 x1, f2 x2) {
+    Probe r;
+    r.d0 = x0 - p.f[F_M0][0];
+    r.d1 = x1 - p.f[F_M1][0];
+    r.d2 = x2 - p.f[F_M2][0];
+    r.q0 = r.d0 * r.d0;
+    r.q1 = r.d1 * r.d1;
+    r.q2 = r.d2 * r.d2;
+    r.dist2 = r.q0 + r.q1;
+    r.dist2 = r.dist2 + r.q2;
+    return r;
+}
+
+// The fast step's update of a wave in which every pixel has one component
+// whose weight is exactly 1 (a pixel that has only ever seen its background:
+// the steady state of most of the picture).  Then
+//     wn = 1 + alpha * (1 - 1) = 1,  wsum = 1,  wscale = 1 / 1 = 1,
+//     W[0] = wn * wscale = 1,        cum = 1 > T: background,
+// all exactly, so the weight arithmetic of weighted_update is skipped whole:
+// only the mean and the variance move.  The deferred sort key's operands are
+// w = 1 and wscale = 1; the kernel notes that once for the wave (mode -1)
+// instead of writing them into `z` every frame.
+__device__ __forceinline__ void unit_update(Mix2 &p, f2 &vsum, const Probe &r,
+                                            float alpha) {
+    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
+    p.f[F_M0][0] = p.f[F_M0][0] + alpha * r.d0;
+    p.f[F_M1][0] = p.f[F_M1][0] + alpha * r.d1;
+    p.f[F_M2][0] = p.f[F_M2][0] + alpha * r.d2;
+    v0 = v0 + alpha * (r.q0 - v0);
+    v1 = v1 + alpha * (r.q1 - v1);
+    v2 = v2 + alpha * (r.q2 - v2);
+    v0.x = __builtin_fmaxf(v0.x, FAST_MINVAR);
+    v0.y = __builtin_fmaxf(v0.y, FAST_MINVAR);
+    v1.x = __builtin_fmaxf(v1.x, FAST_MINVAR);
+    v1.y = __builtin_fmaxf(v1.y, FAST_MINVAR);
+    v2.x = __builtin_fmaxf(v2.x, FAST_MINVAR);
+    v2.y = __builtin_fmaxf(v2.y, FAST_MINVAR);
+    p.f[F_V0][0] = v0;
+    p.f[F_V1][0] = v1;
+    p.f[F_V2][0] = v2;
+    vsum = (v0 + v1) + v2;
+}
+
+// The fast step's update in a wave whose lanes hold at most nc components
 // (wave-uniform; 1, 2 or K).  A component that was never created has weight 0
 // and sort key 0: adding the one to a positive sum and scaling either changes
-// nothing, so those operations are skipped -- same results, and most waves
-// only hold pixels with one mode.  Returns the cumulated weights.
-__device__ __forceinline__ f2 fast_update(Mix2 &p, LazySK &z, f2 &vsum, int nc,
-                                          f2 w, f2 d0, f2 d1, f2 d2, f2 q0,
-                                          f2 q1, f2 q2, float alpha) {
+// nothing, so those operations are skipped -- same results.  Returns the
+// cumulated weights (kHit == 0: a pixel is foreground iff its weights never
+// sum past T); SK[0] is deferred into `z`.
+__device__ __forceinline__ f2 weighted_update(Mix2 &p, LazySK &z, f2 &vsum,
+                                              int nc, const Probe &pr,
+                                              float alpha) {
+    const f2 w = p.f[F_W][0];
     f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
     const f2 one = {1.f, 1.f};
     const f2 wn = w + alpha * (one - w);
@@ -329,17 +383,17 @@ __device__ __forceinline__ f2 fast_update(Mix2 &p, LazySK &z, f2 &vsum, int nc,
     f2 r0;
     r0.x = __builtin_amdgcn_rcpf(wsum.x);
     r0.y = __builtin_amdgcn_rcpf(wsum.y);
-    p.f[F_M0][0] = p.f[F_M0][0] + alpha * d0;
+    p.f[F_M0][0] = p.f[F_M0][0] + alpha * pr.d0;
     const f2 e0 = fma2(-wsum, r0, one);
-    p.f[F_M1][0] = p.f[F_M1][0] + alpha * d1;
+    p.f[F_M1][0] = p.f[F_M1][0] + alpha * pr.d1;
     const f2 r = fma2(e0, r0, r0);
-    p.f[F_M2][0] = p.f[F_M2][0] + alpha * d2;
+    p.f[F_M2][0] = p.f[F_M2][0] + alpha * pr.d2;
     const f2 e1 = fma2(-wsum, r, one);          // q0 = 1 * r = r
-    v0 = v0 + alpha * (q0 - v0);
+    v0 = v0 + alpha * (pr.q0 - v0);
     const f2 q1r = fma2(e1, r, r);
-    v1 = v1 + alpha * (q1 - v1);
+    v1 = v1 + alpha * (pr.q1 - v1);
     const f2 e2 = fma2(-wsum, q1r, one);
-    v2 = v2 + alpha * (q2 - v2);
+    v2 = v2 + alpha * (pr.q2 - v2);
     const f2 wscale = fma2(e2, r, q1r);
     v0.x = __builtin_fmaxf(v0.x, FAST_MINVAR);
     v0.y = __builtin_fmaxf(v0.y, FAST_MINVAR);
@@ -374,120 +428,58 @@ __device__ __forceinline__ f2 fast_update(Mix2 &p, LazySK &z, f2 &vsum, int nc,
     return cum;
 }
 
-// The update of a fast step in a wave in which every pixel has one component
-// and that component's weight is exactly 1 (a pixel that has only ever seen
-// its background: the steady state of most of the picture).  Then
-//     wn = 1 + alpha * (1 - 1) = 1,  wsum = 1,  wscale = 1 / 1 = 1,
-//     W[0] = wn * wscale = 1,        cum = 1 > T: background,
-// all exactly, so the weight arithmetic of fast_update is skipped whole and
-// only the mean and the variance move.
-__device__ __forceinline__ void unit_update(Mix2 &p, LazySK &z, f2 &vsum, f2 d0,
-                                            f2 d1, f2 d2, f2 q0, f2 q1, f2 q2,
-                                            float alpha) {
-    f2 v0 = p.f[F_V0][0], v1 = p.f[F_V1][0], v2 = p.f[F_V2][0];
-    p.f[F_M0][0] = p.f[F_M0][0] + alpha * d0;
-    p.f[F_M1][0] = p.f[F_M1][0] + alpha * d1;
-    p.f[F_M2][0] = p.f[F_M2][0] + alpha * d2;
-    v0 = v0 + alpha * (q0 - v0);
-    v1 = v1 + alpha * (q1 - v1);
-    v2 = v2 + alpha * (q2 - v2);
-    v0.x = __builtin_fmaxf(v0.x, FAST_MINVAR);
-    v0.y = __builtin_fmaxf(v0.y, FAST_MINVAR);
-    v1.x = __builtin_fmaxf(v1.x, FAST_MINVAR);
-    v1.y = __builtin_fmaxf(v1.y, FAST_MINVAR);
-    v2.x = __builtin_fmaxf(v2.x, FAST_MINVAR);
-    v2.y = __builtin_fmaxf(v2.y, FAST_MINVAR);
-    p.f[F_V0][0] = v0;
-    p.f[F_V1][0] = v1;
-    p.f[F_V2][0] = v2;
-    z.w = f2{1.f, 1.f};
-    z.scale = f2{1.f, 1.f};
-    vsum = (v0 + v1) + v2;
-}
-
-// Both pixels of `p` against their component 0.  Returns true if both
-// matched: model updated, SK[0] deferred into `z`, cum = the cumulated
-// weights of the two pixels (kHit == 0: a pixel is foreground iff its weights
-// never sum past T).  False with `p` and `cum` untouched if either did not.
-// nc (wave-uniform): no lane of the wave holds more than nc components;
-// unit (wave-uniform): nc == 1 and every weight W[0] is exactly 1.
-// vsum: (var0 + var1) + var2 of component 0, carried from frame to frame (the
-// value the threshold needs is the one the previous step's update ended
-// with); recomputed by the caller after a general step.
-__device__ __forceinline__ bool mog_step_pair0(Mix2 &p, LazySK &z, f2 &vsum,
-                                               int nc, bool unit, f2 x0, f2 x1,
-                                               f2 x2, float alpha, f2 &cum) {
-    const f2 w = p.f[F_W][0];
-    const f2 d0 = x0 - p.f[F_M0][0];
-    const f2 d1 = x1 - p.f[F_M1][0];
-    const f2 d2 = x2 - p.f[F_M2][0];
-    const f2 q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-    f2 dist2 = q0 + q1;
-    dist2 = dist2 + q2;
-    const f2 thr = FAST_VT * vsum;
-    // weights are never negative: their bit patterns order like the values
-    const unsigned wmin = min(__float_as_uint(w.x), __float_as_uint(w.y));
-    const bool hit = wmin >= __float_as_uint(FLT_EPSILON) &&
-                     dist2.x < thr.x && dist2.y < thr.y;
-    if (!hit) return false;
-    if (unit) {
-        asm volatile("; unit weights");
-        unit_update(p, z, vsum, d0, d1, d2, q0, q1, q2, alpha);
-        cum = f2{1.f, 1.f};
-    } else {
-        cum = fast_update(p, z, vsum, nc, w, d0, d1, d2, q0, q1, q2, alpha);
-    }
-    return true;
+// Lane `lane_sel` of a0 .. a3 set to the (wave-uniform) words w0 .. w3: four
+// v_writelane_b32 with the lane number in M0 (a VOP3 takes one scalar
+// register operand only, and the lane is not a compile-time constant).  M0 is
+// saved and restored inside the statement.
+__device__ __forceinline__ void write_lane_x4(unsigned &a0, unsigned &a1,
+                                              unsigned &a2, unsigned &a3,
+                                              int lane_sel, unsigned w0,
+                                              unsigned w1, unsigned w2,
+                                              unsigned w3) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %4, m0\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %0, %5, m0\n\t"
+        "v_writelane_b32 %1, %6, m0\n\t"
+        "v_writelane_b32 %2, %7, m0\n\t"
+        "v_writelane_b32 %3, %8, m0\n\t"
+        "s_mov_b32 m0, %4"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&s"(keep)
+        : "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(lane_sel));
 }
 
 // ---------------------------------------------------------------------------
 // Fast path: contiguous frames, N % 2 == 0.  Each lane owns 2 neighbouring
-// pixels (a 6-byte load and a 2-byte store per frame), the model is read once
-// and written once per launch.
+// pixels (a 6-byte load per frame), the model is read once and written once
+// per launch.
 //
-// What bounds it (MI355X, 1080p, 128 frames per launch, rocprofv3 counters):
-// on a static scene the four SIMDs of every CU issue vector instructions
-// back to back (~90 per wave and frame at 4 cycles each; 0.39 ms per launch,
-// 2.4 TB/s of HBM traffic) -- VALU issue.  A scene with moving objects adds
-// the general step for the waves that contain a pixel off its background
-// mode (~8 % of wave-frames with 128-pixel runs per wave, ~3 % with 32 x 4
-// tiles) and a tail: such waves run several times longer than the others and
-// there are only four waves per slot in a launch.  Hence the tiles, one wave
-// per workgroup, and the launch order (mog_order_k).  4 waves per SIMD need
-// 128 VGPRs: the rarely used half of the model sits in LDS, DEPTH frames of
-// input are requested ahead (every frame's bytes are an HBM miss).
-// ---------------------------------------------------------------------------
-// acc with lanes first .. first + 3 set to the (wave-uniform) words w0 .. w3:
-// four v_writelane_b32 with the lane number in M0 (a VOP3 takes one SGPR
-// operand only, and `first` is not a compile-time constant).  M0 is saved and
-// restored inside the statement.
-__device__ __forceinline__ unsigned write_4_lanes(unsigned acc, int first,
-                                                  unsigned w0, unsigned w1,
-                                                  unsigned w2, unsigned w3) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %1, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %0, %2, m0\n\t"
-        "s_add_u32 m0, m0, 1\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %0, %3, m0\n\t"
-        "s_add_u32 m0, m0, 1\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %0, %4, m0\n\t"
-        "s_add_u32 m0, m0, 1\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 %0, %5, m0\n\t"
-        "s_mov_b32 m0, %1"
-        : "+v"(acc), "=&s"(keep)
-        : "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(first)
-        : "scc");
-    return acc;
-}
-
+// What bounds it (MI355X, 1080p, 128 frames per launch; tools/ubench,
+// profiles/): instruction issue -- vector AND scalar.  A scalar instruction
+// (mask logic, compares, branches, address arithmetic, waits) takes a SIMD's
+// issue slot for about as long as a vector one, so the frame step is written
+// for few instructions of either kind on the path nearly every wave takes:
+//   * mode <= 0 ("unit"): every pixel of the wave has one component of weight
+//     exactly 1 and matches it: 26 packed + 14 plain vector instructions and a
+//     handful of scalar ones per frame, no mask manipulation (unit_update);
+//   * all lanes match their component 0 but weights are not trivial:
+//     weighted_update, not masked either;
+//   * otherwise lanes that match take weighted_update under their mask and the
+//     others the general step (mog_step, the oracle's loop verbatim).
+// Pixels off the first path come in compact 2-D groups (moving objects, their
+// edges), hence the 32 x 4 pixel tiles per wave; such waves run several times
+// longer than the others and there are only ~8 waves per slot in a launch,
+// hence one wave per workgroup and the launch order (mog_order_k).  4 waves
+// per SIMD need <= 128 VGPRs: the rarely used part of the model sits in LDS;
+// DEPTH frames of input (and their learning rates) are requested ahead.
+//
+// DEPTH > 1 needs nframes % DEPTH == 0 (the host splits a ragged batch);
+// alpha_table holds HISTORY + 4 entries, 1 / min(i + 1, HISTORY).
 // MASKS: byte masks are written (hk_mog_apply_batch); TILES: the 1-bit tile
 // words are (hk_mog_apply_batch_tiles, TILED geometry only).
+// ---------------------------------------------------------------------------
 template <int WAVES, int DEPTH, bool TILED, bool MASKS, bool TILES>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
@@ -499,6 +491,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     int *__restrict__ cost, unsigned *__restrict__ tiles,
     long tile_words_per_frame) {
     static_assert(!TILES || TILED, "tile words need the tiled geometry");
+    static_assert(DEPTH <= 4, "alpha_table is padded by 4 entries");
     // One wave per workgroup, so that a finished wave's slot and LDS are
     // reused at once (waves of one workgroup end at very different times).
     // A "group" is 4 units of 128 pixels that share cache lines of the frame
@@ -526,14 +519,14 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
         i0 = (ty * 4 + (lane >> 4)) * width + tx * 32 + (lane & 15) * 2;
     }
     // TILES: the wave's tile takes 4 words per frame in the 1-bit output (see
-    // hk_mog_apply_batch_tiles).  The words of 16 frames are collected in one
-    // register, lane L = word L & 3 of frame L >> 2 of the group of 16, and
-    // stored together.
+    // hk_mog_apply_batch_tiles).  The words of 64 frames are collected in
+    // four registers, lane L = frame L of the group of 64, and stored as one
+    // 16-byte store per lane.  The registers start at zero and a frame without
+    // foreground leaves its lane alone.
     unsigned *tile_dst = nullptr;
-    unsigned tile_acc = 0u;
+    unsigned ta0 = 0u, ta1 = 0u, ta2 = 0u, ta3 = 0u;
     if (TILES)
-        tile_dst = tiles + (g >> 6) * 4 + (lane & 3) +
-                   (long)(lane >> 2) * tile_words_per_frame;
+        tile_dst = tiles + (g >> 6) * 4 + (long)lane * tile_words_per_frame;
 
     // A component that was never created has weight 0 and all-zero fields
     // (the model starts zeroed, components are created with weight w0 > 0 and
@@ -573,135 +566,214 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     LazySK lazy;
     lazy.w = lazy.scale = f2{0.f, 0.f};
     int slow_steps = 0;     // frames in which this wave left the fast step
-    // variance sum of component 0 (the fast step's threshold operand) and
-    // the largest number of components any lane of the wave holds (1, 2 or
-    // "up to 5"): both change only in the general step
+    const unsigned long long all_lanes = __builtin_amdgcn_ballot_w64(true);
+    // variance sum of component 0: the fast step's threshold operand, carried
+    // from frame to frame (the value the test needs is the one the previous
+    // step's update ended with) and recomputed after a general step
     f2 vsum = (px.f[F_V0][0] + px.f[F_V1][0]) + px.f[F_V2][0];
-    auto count_components = [&]() {
+    // mode (wave-uniform): the largest number of components any lane holds
+    // (1, 2, or K for "more"), or, if that is 1 and every W[0] is exactly 1
+    // (see unit_update), 0; -1 = 0 and every lane's deferred sort key has the
+    // operands w = 1, wscale = 1 (what unit_update leaves without writing it)
+    auto wave_mode = [&]() {
         const bool two = px.f[F_W][1].x != 0.f || px.f[F_W][1].y != 0.f;
         const bool more = px.f[F_W][2].x != 0.f || px.f[F_W][2].y != 0.f;
-        return __builtin_amdgcn_ballot_w64(more) ? K
-               : __builtin_amdgcn_ballot_w64(two) ? 2 : 1;
+        if (__builtin_amdgcn_ballot_w64(more)) return K;
+        if (__builtin_amdgcn_ballot_w64(two)) return 2;
+        return __builtin_amdgcn_ballot_w64(px.f[F_W][0].x != 1.f ||
+                                           px.f[F_W][0].y != 1.f) ? 1 : 0;
     };
-    int nc = count_components();
-    // nc == 1 and every W[0] == 1 (see unit_update); while a wave with single
-    // components is not there yet it is looked at again after every frame
-    auto unit_weights = [&]() {
-        return nc == 1 &&
-               __builtin_amdgcn_ballot_w64(px.f[F_W][0].x != 1.f ||
-                                           px.f[F_W][0].y != 1.f) == 0;
-    };
-    bool unit = unit_weights();
+    int mode = wave_mode();
 
     // The 6 input bytes of a frame are far from those of the next frame, so
     // every load is an HBM miss (~2 us under load): the frames of the next
-    // group of DEPTH are requested while this group is processed.
+    // group of DEPTH are requested while this group is processed, and so are
+    // their learning rates.
     const uint8_t *src = bgr + i0 * 3;
     uint8_t *dst = mask + i0;
-    unsigned cur[DEPTH][2], nxt[DEPTH][3];
+    unsigned cur[DEPTH][2], nxt[DEPTH][2];
+    float cur_alpha[DEPTH], nxt_alpha[DEPTH];
+    // A pair's 6 bytes are fetched by one 8-byte load (2-byte aligned; the 2
+    // bytes beyond belong to the next pair and are ignored) -- except in the
+    // wave that holds the last pair of the picture, which would read past
+    // the end of the last frame: that one takes three 2-byte loads.
+    const bool last_wave =
+        __builtin_amdgcn_ballot_w64(i0 + 2 >= n_pixels) != 0;
+    auto fetch = [&](int f, unsigned (&d)[2]) {
+        const uint8_t *p = src + (long)f * bgr_frame_stride;
+        if (!last_wave) {
+            typedef unsigned u2a __attribute__((ext_vector_type(2), aligned(2)));
+            const u2a v = *reinterpret_cast<const u2a *>(p);
+            d[0] = v.x;
+            d[1] = v.y;
+        } else {
+            const unsigned short *s16 =
+                reinterpret_cast<const unsigned short *>(p);
+            d[0] = s16[0] | ((unsigned)s16[1] << 16);
+            d[1] = s16[2];
+        }
+    };
+    auto alphas_of = [&](int t, float (&a)[DEPTH]) {
+        int i = frames_before + t;          // frame t has n = i + 1
+        i = i < HISTORY ? i : HISTORY;
 #pragma unroll
-    for (int j = 0; j < DEPTH; ++j) {
-        const int f = j < nframes ? j : nframes - 1;
-        const unsigned short *s16 = reinterpret_cast<const unsigned short *>(
-            src + (long)f * bgr_frame_stride);
-        cur[j][0] = s16[0] | ((unsigned)s16[1] << 16);
-        cur[j][1] = s16[2];
-    }
+        for (int j = 0; j < DEPTH; ++j) a[j] = alpha_table[i + j];
+    };
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) fetch(j < nframes ? j : nframes - 1, cur[j]);
+    alphas_of(0, cur_alpha);
     for (int t0 = 0; t0 < nframes; t0 += DEPTH) {
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            int f = t0 + DEPTH + j;
-            f = f < nframes ? f : nframes - 1;
-            const unsigned short *s16 = reinterpret_cast<const unsigned short *>(
-                src + (long)f * bgr_frame_stride);
-            nxt[j][0] = s16[0];
-            nxt[j][1] = s16[1];
-            nxt[j][2] = s16[2];
+            const int f = t0 + DEPTH + j;
+            fetch(f < nframes ? f : nframes - 1, nxt[j]);
         }
+        alphas_of(t0 + DEPTH, nxt_alpha);
+        // frame j of the group as three pairs of floats
+        auto decode = [&](int j, f2 &x0, f2 &x1, f2 &x2) {
+            const unsigned c01 = cur[j][0], c2 = cur[j][1];
+            // bytes b0 g0 r0 b1 | g1 r1 (and two of the next pair)
+            x0.x = (float)(c01 & 255u);
+            x1.x = (float)((c01 >> 8) & 255u);
+            x2.x = (float)((c01 >> 16) & 255u);
+            x0.y = (float)(c01 >> 24);
+            x1.y = (float)(c2 & 255u);
+            x2.y = (float)((c2 >> 8) & 255u);
+        };
+        // The frames of the group a wave in unit mode gets through with every
+        // lane near its component: straight-line code on the mean and the
+        // variance alone, up to the first frame that does not qualify.
+        int unit_frames = 0;
+        if (mode <= 0) {
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int t = t0 + j;
-            if (t < nframes) {
-                int n = frames_before + t + 1;
-                n = n < HISTORY ? n : HISTORY;
-                const float alpha = alpha_table[n - 1];
-                const unsigned c01 = cur[j][0], c2 = cur[j][1];
-                // bytes b0 g0 | r0 b1 | g1 r1
+            for (int j = 0; j < DEPTH; ++j) {
+                if (unit_frames == j) {
+                    f2 x0, x1, x2;
+                    decode(j, x0, x1, x2);
+                    const Probe pr = probe0(px, x0, x1, x2);
+                    const f2 thr = FAST_VT * vsum;
+                    // (a ballot of a compare is the compare's own result;
+                    // a ballot of their conjunction would cost two vector
+                    // instructions more)
+                    const unsigned long long near =
+                        __builtin_amdgcn_ballot_w64(pr.dist2.x < thr.x) &
+                        __builtin_amdgcn_ballot_w64(pr.dist2.y < thr.y);
+                    if (near == all_lanes) {
+                        asm volatile("; unit step");
+                        unit_update(px, vsum, pr, cur_alpha[j]);
+                        unit_frames = j + 1;
+                        if (MASKS)      // all background
+                            *reinterpret_cast<unsigned short *>(
+                                dst + (long)(t0 + j) * mask_frame_stride) = 0;
+                    }
+                }
+            }
+            if (unit_frames) mode = -1;
+        }
+        if (unit_frames < DEPTH) {
+            if (mode < 0) {         // see `mode`
+                lazy.w = lazy.scale = f2{1.f, 1.f};
+                mode = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                if (j < unit_frames) continue;
+                const int t = t0 + j;
+                const float alpha = cur_alpha[j];
                 f2 x0, x1, x2;
-                x0.x = (float)(c01 & 255u);
-                x1.x = (float)((c01 >> 8) & 255u);
-                x2.x = (float)((c01 >> 16) & 255u);
-                x0.y = (float)(c01 >> 24);
-                x1.y = (float)(c2 & 255u);
-                x2.y = (float)(c2 >> 8);
-                // cum: > T = background.  The fast step leaves each
-                // pixel's cumulated weights there, the general step a
-                // stand-in on the right side of T, so that one compare per
-                // pixel after the two paths have joined yields the wave's
-                // foreground bits (a boolean merged across the paths would
-                // cost two more vector instructions each)
+                decode(j, x0, x1, x2);
+                const Probe pr = probe0(px, x0, x1, x2);
+                const f2 thr = FAST_VT * vsum;
+                // weights are never negative: their bit patterns order like
+                // the values
+                const unsigned wmin = min(__float_as_uint(px.f[F_W][0].x),
+                                          __float_as_uint(px.f[F_W][0].y));
+                const bool hit = pr.dist2.x < thr.x && pr.dist2.y < thr.y &&
+                                 wmin >= __float_as_uint(FLT_EPSILON);
+                const unsigned long long hits =
+                    __builtin_amdgcn_ballot_w64(pr.dist2.x < thr.x) &
+                    __builtin_amdgcn_ballot_w64(pr.dist2.y < thr.y) &
+                    __builtin_amdgcn_ballot_w64(
+                        wmin >= __float_as_uint(FLT_EPSILON));
+                const int nc = mode < 1 ? 1 : mode;
+                // cum > T = background.  The fast step leaves each pixel's
+                // cumulated weights there, the general step a stand-in on
+                // the right side of T, so that one compare per pixel after
+                // the paths have joined yields the wave's foreground bits.
                 f2 cum;
-                const bool fast = mog_step_pair0(px, lazy, vsum, nc, unit, x0,
-                                                 x1, x2, alpha, cum);
-                const bool any_slow = __builtin_amdgcn_ballot_w64(!fast) != 0;
-                if (!fast) {
-                    // the launch ends when its slowest wave does: waves in
-                    // the long general step go first at instruction issue
-                    __builtin_amdgcn_s_setprio(3);
-                    materialise_sk0(px, lazy, vsum);
-                    Lane<0> l0{px};
-                    Lane<1> l1{px};
-                    cum.x = mog_step(l0, x0.x, x1.x, x2.x, alpha, c) ? 0.f
-                                                                      : 1.f;
-                    cum.y = mog_step(l1, x0.y, x1.y, x2.y, alpha, c) ? 0.f
-                                                                      : 1.f;
-                    vsum = (px.f[F_V0][0] + px.f[F_V1][0]) + px.f[F_V2][0];
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                const bool f0 = !(cum.x > FAST_T), f1 = !(cum.y > FAST_T);
-                if (any_slow) {
+                bool recount = false;
+                if (hits == all_lanes) {
+                    asm volatile("; every lane on its first component");
+                    cum = weighted_update(px, lazy, vsum, nc, pr, alpha);
+                } else {
+                    if (hit) {
+                        cum = weighted_update(px, lazy, vsum, nc, pr, alpha);
+                    } else {
+                        // the launch ends when its slowest wave does: waves
+                        // in the long general step go first at instruction
+                        // issue
+                        __builtin_amdgcn_s_setprio(3);
+                        materialise_sk0(px, lazy, vsum);
+                        Lane<0> l0{px};
+                        Lane<1> l1{px};
+                        cum.x = mog_step(l0, x0.x, x1.x, x2.x, alpha, c)
+                                    ? 0.f : 1.f;
+                        cum.y = mog_step(l1, x0.y, x1.y, x2.y, alpha, c)
+                                    ? 0.f : 1.f;
+                        vsum = (px.f[F_V0][0] + px.f[F_V1][0]) +
+                               px.f[F_V2][0];
+                        __builtin_amdgcn_s_setprio(0);
+                    }
                     ++slow_steps;
-                    nc = count_components();
-                    unit = false;
+                    recount = true;
                 }
-                if (!unit) unit = unit_weights();
+                // components only ever get more, and only in the general
+                // step; a wave of single components is looked at after every
+                // frame until its weights are all 1
+                if (recount || mode == 1) mode = wave_mode();
+                const bool f0 = !(cum.x > FAST_T), f1 = !(cum.y > FAST_T);
                 if (MASKS) {
-                    const unsigned m = (f0 ? 255u : 0u) | (f1 ? 255u << 8 : 0u);
+                    const unsigned m = (f0 ? 255u : 0u) |
+                                       (f1 ? 255u << 8 : 0u);
                     *reinterpret_cast<unsigned short *>(
                         dst + (long)t * mask_frame_stride) = (unsigned short)m;
                 }
                 if (TILES) {
-                    const unsigned long long fg0 =
+                    const unsigned long long b0 =
                         __builtin_amdgcn_ballot_w64(f0);
-                    const unsigned long long fg1 =
+                    const unsigned long long b1 =
                         __builtin_amdgcn_ballot_w64(f1);
-                    tile_acc = write_4_lanes(tile_acc, (t & 15) * 4,
-                                             (unsigned)fg0,
-                                             (unsigned)(fg0 >> 32),
-                                             (unsigned)fg1,
-                                             (unsigned)(fg1 >> 32));
+                    if ((b0 | b1) != 0ull)
+                        write_lane_x4(ta0, ta1, ta2, ta3, t & 63, (unsigned)b0,
+                                      (unsigned)(b0 >> 32), (unsigned)b1,
+                                      (unsigned)(b1 >> 32));
                 }
             }
         }
         if (TILES) {
-            // frames [first, t0 + DEPTH) of the current group of 16 are in
-            // tile_acc; store when the group is complete or the batch ends
+            // frames [first, done) of the current group of 64 are in the
+            // accumulators; store when the group is complete or the batch ends
             const int done = t0 + DEPTH < nframes ? t0 + DEPTH : nframes;
-            if ((done & 15) == 0 || done == nframes) {
-                const int first = (done - 1) & ~15;
-                if (first + (lane >> 2) < done)
-                    tile_dst[(long)first * tile_words_per_frame] = tile_acc;
+            if ((done & 63) == 0 || done == nframes) {
+                const int first = (done - 1) & ~63;
+                if (first + lane < done)
+                    *reinterpret_cast<uint4 *>(
+                        tile_dst + (long)first * tile_words_per_frame) =
+                        make_uint4(ta0, ta1, ta2, ta3);
+                ta0 = ta1 = ta2 = ta3 = 0u;
             }
         }
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            cur[j][0] = nxt[j][0] | (nxt[j][1] << 16);
-            cur[j][1] = nxt[j][2];
+            cur[j][0] = nxt[j][0];
+            cur[j][1] = nxt[j][1];
+            cur_alpha[j] = nxt_alpha[j];
         }
     }
 
     if (cost && threadIdx.x == 0 && slow_steps)
         atomicMax(&cost[group], slow_steps);
+    if (mode < 0) lazy.w = lazy.scale = f2{1.f, 1.f};
     materialise_sk0(px, lazy, vsum);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -884,7 +956,7 @@ struct hk_mog {
     long n_pixels = 0;
     int nframes = 0;
     float *planes = nullptr;        // [NPLANES][n_pixels]
-    float *alpha_table = nullptr;   // [HISTORY]
+    float *alpha_table = nullptr;   // [ALPHA_ENTRIES]
     int *cost = nullptr;            // [n_groups] slow frames, last batch launch
     int *order = nullptr;           // [n_groups] launch order, see mog_order_k
     int n_groups = 0;
@@ -915,7 +987,7 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
     hipError_t e = hipMalloc((void **)&m->planes, bytes);
     if (e == hipSuccess) e = hipMemset(m->planes, 0, bytes);
     if (e == hipSuccess)
-        e = hipMalloc((void **)&m->alpha_table, sizeof(float) * HISTORY);
+        e = hipMalloc((void **)&m->alpha_table, sizeof(float) * ALPHA_ENTRIES);
     m->n_groups = (int)((m->n_pixels / 2 + 255) / 256);
     if (e == hipSuccess)
         e = hipMalloc((void **)&m->cost, sizeof(int) * 2 * m->n_groups);
@@ -924,8 +996,9 @@ extern "C" int hk_mog_create(int width, int height, int device, hk_mog **out) {
         e = hipMemset(m->cost, 0, sizeof(int) * 2 * m->n_groups);
     }
     if (e == hipSuccess) {
-        float tbl[HISTORY];
-        for (int i = 0; i < HISTORY; ++i) tbl[i] = (float)(1. / (i + 1));
+        float tbl[ALPHA_ENTRIES];
+        for (int i = 0; i < ALPHA_ENTRIES; ++i)
+            tbl[i] = (float)(1. / (i < HISTORY ? i + 1 : HISTORY));
         e = hipMemcpy(m->alpha_table, tbl, sizeof(tbl), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
@@ -1004,6 +1077,7 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
                         "hk_mog_apply_batch: frame stride smaller than a "
                         "frame");
     const long N = m.n_pixels;
+    int frames_before = m.frames_before;
     const bool fast =
         bgr_pitch == 3L * m.width && mask_pitch == m.width && N % 2 == 0 &&
         ((uintptr_t)bgr_dev & 1) == 0 && ((uintptr_t)mask_dev & 1) == 0 &&
@@ -1019,7 +1093,7 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
                            dim3(64), 0, s, m.planes, N, m.width,              \
                            (const uint8_t *)bgr_dev,                          \
                            bgr_frame_stride, (uint8_t *)mask_dev,             \
-                           mask_frame_stride, nframes, m.frames_before,       \
+                           mask_frame_stride, nframes, frames_before,         \
                            m.alpha_table, *m.c, m.n_groups, order, cost,      \
                            (unsigned *)tiles_dev, tile_words)
         const bool tileable = m.width % 32 == 0 && m.height % 4 == 0;
@@ -1043,14 +1117,30 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
             }
             *m.frames_of_cost = nframes;
         }
-        if (nframes <= 4) {
-            if (tiles_dev) HK_MOG_LAUNCH(4, 1, true, false, true);
-            else if (tileable) HK_MOG_LAUNCH(4, 1, true, true, false);
-            else HK_MOG_LAUNCH(4, 1, false, true, false);
-        } else {
+        // the 4-frame-group kernel takes whole groups; what is left over
+        // (and short batches) goes through the frame-at-a-time kernel
+        const int n4 = nframes > 4 ? nframes & ~3 : 0;
+        if (n4) {
+            const int nframes_all = nframes;
+            nframes = n4;
             if (tiles_dev) HK_MOG_LAUNCH(4, 4, true, false, true);
             else if (tileable) HK_MOG_LAUNCH(4, 4, true, true, false);
             else HK_MOG_LAUNCH(4, 4, false, true, false);
+            HK_LAUNCH_CHECK("mog_batch2_k");
+            nframes = nframes_all - n4;
+            frames_before += n4;
+            bgr_dev = (const uint8_t *)bgr_dev + (long)n4 * bgr_frame_stride;
+            if (mask_dev)
+                mask_dev = (uint8_t *)mask_dev + (long)n4 * mask_frame_stride;
+            if (tiles_dev)
+                tiles_dev = (unsigned *)tiles_dev + (long)n4 * tile_words;
+            order = nullptr;        // scheduling only: not worth it here,
+            cost = nullptr;         // and the costs are those of the groups
+        }
+        if (nframes > 0) {
+            if (tiles_dev) HK_MOG_LAUNCH(4, 1, true, false, true);
+            else if (tileable) HK_MOG_LAUNCH(4, 1, true, true, false);
+            else HK_MOG_LAUNCH(4, 1, false, true, false);
         }
 #undef HK_MOG_LAUNCH
         HK_LAUNCH_CHECK("mog_batch2_k");
@@ -1136,7 +1226,8 @@ constexpr int STATIC_MAX_GROUPS = (int)((STATIC_MAX_PIXELS / 2 + 255) / 256);
 constexpr size_t STATIC_ALPHA_BYTES = 1024;             // HISTORY floats, padded
 constexpr size_t STATIC_SCRATCH_BYTES =
     STATIC_ALPHA_BYTES + 2 * sizeof(int) * (size_t)STATIC_MAX_GROUPS;   // 128 KB
-static_assert(sizeof(float) * HISTORY <= STATIC_ALPHA_BYTES, "alpha table");
+static_assert(sizeof(float) * ALPHA_ENTRIES <= STATIC_ALPHA_BYTES,
+              "alpha table");
 
 }  // namespace
 
@@ -1144,11 +1235,13 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 namespace {
 
-// alpha[i] = (float)(1. / (i + 1)), as hk_mog_create computes it on the host
+// alpha[i] = (float)(1. / min(i + 1, HISTORY)), as hk_mog_create computes it on
+// the host
 // (IEEE double division, then one rounding to float).
 __global__ __launch_bounds__(256) void mog_alpha_table_k(float *alpha) {
     const int i = threadIdx.x;
-    if (i < HISTORY) alpha[i] = (float)(1. / (double)(i + 1));
+    if (i < ALPHA_ENTRIES)
+        alpha[i] = (float)(1. / (double)(i < HISTORY ? i + 1 : HISTORY));
 }
 
 constexpr int STATIC_MAX_DEVICES = 64;
