@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <memory>
+#include <limits>
 #include <mutex>
 #include <thread>
 
@@ -318,6 +319,18 @@ public:
         maxd_sq_lo_ = maxd_ * maxd_ * (1 - 1e-12);
         maxd_sq_hi_ = maxd_ * maxd_ * (1 + 1e-12);
         rot_ = rotation(c);
+        // what eval_arc() will ask of a finished trial arc's e
+        // (acceleration_ok), for the early exit of doomed trials
+        if (c.has_g) {
+            e_lo_ = 0.5 * (1 - c.p.g_window) * c.g;
+            e_hi_ = 0.5 * (1 + c.p.g_window) * c.g;
+        } else {
+            const double max_cm_per_px = c.p.max_frame_height_cm / c.H;
+            e_lo_ = 0.5 * G_CM / (max_cm_per_px * (c.fps * c.fps));
+            e_hi_ = std::numeric_limits<double>::infinity();
+        }
+        prune_ok_ = rot_.s == 0.0 && rot_.c == 1.0 && std::isfinite(e_lo_) &&
+                    !getenv("HK_STEP3_NO_PRUNE");
         if (c.has_g) {
             e0_ = 0.5 * c.g;
         } else {
@@ -922,7 +935,10 @@ private:
         for (size_t k = 0; k < m; ++k)
             if (k == 0 || c.frame[s.cand[k]] != c.frame[s.cand[k - 1]])
                 ++groups;
-        int *out = m ? s.pool_alloc(2 * m + 2 * groups) : nullptr;
+        // the grouped copy carries each tag's place in the seed queue with
+        // it: half of the frontier candidates are dismissed on that alone
+        // (seeds before the current one), without touching the tag's record
+        int *out = m ? s.pool_alloc(3 * m + 2 * groups) : nullptr;
         for (size_t k = 0; k < m; ++k) out[k] = s.cand[(size_t)s.order[k]];
         int *grp = out + m, *count = nullptr;
         size_t w = 0;
@@ -934,6 +950,7 @@ private:
                 *count = 0;
             }
             grp[w++] = j;
+            grp[w++] = qpos_[(size_t)j];
             ++*count;
         }
         nb_ptr_[(size_t)i] = out;
@@ -967,8 +984,9 @@ private:
                 p += 2;
                 if (s.taken[g] != s.stamp)
                     for (int q = 0; q < k; ++q)
-                        add_one_to_frontier(p[q], pos, s, res);
-                p += k;
+                        if (p[2 * q + 1] >= pos)
+                            add_one_to_frontier(p[2 * q], pos, s, res);
+                p += 2 * k;
             }
             return;
         }
@@ -1008,6 +1026,39 @@ private:
 
     // One seed: try its neighbours in order until one pair grows into an
     // acceptable arc (reference tracker.py:521-625).
+    // A trial arc can only be accepted if, when it stops growing, every
+    // member lies within max_distance_pixels of it (the check after every
+    // refit) and its e passes acceleration_ok (eval_arc).  Members are never
+    // dropped, so if NO parabola y = c + e t^2 with e in the accepted window
+    // passes within max_distance_pixels of three of the current members (in y
+    // alone: with zero tilt a tag's distance to the arc is at least its
+    // vertical offset), none will do so for any larger set either: the trial
+    // is doomed and is given up at once -- same outcome (no arc), without the
+    // growth steps in between, most of which belong to long trials along
+    // slowly moving clutter whose fitted e is ~0.
+    // For members at frames f1 < f2 < f3 the second divided difference of
+    // their y is e + that of their offsets, so e lies within
+    // D +- maxd * sum |coefficients|; likewise that of x is 0 +- the same.
+    bool doomed(const Scratch &s) const {
+        const size_t n = s.members.size();
+        if (!prune_ok_ || n < 3) return false;
+        const size_t i1 = 0, i2 = n / 2, i3 = n - 1;
+        const double f1 = s.mf[i1], f2 = s.mf[i2], f3 = s.mf[i3];
+        const double c1 = 1.0 / ((f2 - f1) * (f3 - f1));
+        const double c2 = 1.0 / ((f2 - f1) * (f3 - f2));
+        const double c3 = 1.0 / ((f3 - f1) * (f3 - f2));
+        if (!(c1 > 0 && c2 > 0 && c3 > 0)) return false;   // frames not distinct
+        const double slack = maxd_ * (c1 + c2 + c3) * (1 + 1e-9) + 1e-12;
+        const double dy = s.my[i1] * c1 - s.my[i2] * c2 + s.my[i3] * c3;
+        const double dx = s.mx[i1] * c1 - s.mx[i2] * c2 + s.mx[i3] * c3;
+        if (!(dy == dy) || !(dx == dx)) return false;       // NaN coordinates
+        const double tol = 1e-9 * (std::fabs(dy) + std::fabs(dx) + 1.0);
+        if (dy + slack + tol < e_lo_) return true;
+        if (dy - slack - tol > e_hi_) return true;
+        if (std::fabs(dx) - slack - tol > 0) return true;
+        return false;
+    }
+
     // Squared distance of a tag at (frame f, x, y) to the arc: the operations
     // of arc_tag_distance, minus the final square root.
     double dist_sq(const Arc &arc, double f, double x, double y) const {
@@ -1175,6 +1226,10 @@ private:
                 s.mx.insert(s.mx.begin() + (long)at, tb.x);
                 s.my.insert(s.my.begin() + (long)at, tb.y);
                 s.taken[tb.frame] = s.stamp;
+                if (doomed(s)) {
+                    bad = true;
+                    break;
+                }
                 { S3P_T0;
                 add_neighbors_to_frontier(best, pos, s, res);
                 S3P_ADD(2); }
@@ -1294,6 +1349,8 @@ private:
                          atoi(getenv("HK_STEP3_SIMD")) == 0);
     bool has_vmax_ = false;
     double v_max_ = 0, maxd_ = 0, maxd_sq_lo_ = 0, maxd_sq_hi_ = 0, e0_ = 0;
+    double e_lo_ = 0, e_hi_ = 0;        // window of acceleration_ok, see doomed()
+    bool prune_ok_ = false;
     Rot rot_{0, 1};
 };
 
