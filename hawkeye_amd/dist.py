@@ -21,6 +21,8 @@ in CPU tests).
 The exchange is tiny (<= ~50 events x 16 B per frame) and latency-bound, so a
 direct send to rank 0 inside one group call is used, not a ring collective.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -80,7 +82,8 @@ def gather_events(records, device=None, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if device is None:
-        device = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+        device = torch.device('cuda', default_device()) \
+            if dist.get_backend(group) == 'nccl' else 'cpu'
     mine = torch.from_numpy(np.ascontiguousarray(records, np.int32)).to(device)
     count = torch.tensor([mine.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(count) for _ in range(world)]
@@ -121,34 +124,70 @@ def detect_segment(source, detector, first, keep_from, end, chunk=128):
     return out[keep_from - first:]
 
 
-def scan_time_segmented(make_source, warmup=400, device=0, group=None,
+def default_device():
+    """The GPU of this rank: LOCAL_RANK when the launcher exported it (one
+    process per GPU), else torch's current device."""
+    local = os.environ.get('LOCAL_RANK')
+    if local is not None:
+        return int(local)
+    return torch.cuda.current_device()
+
+
+def detect_time_segmented(make_source, warmup=400, device=None, group=None,
+                          chunk=128, detector=None):
+    """Step 2 of one clip over all ranks of `group`: rank r detects frames
+    [start_r - warmup, end_r) of `make_source()` (a frame source with seek())
+    on its own GPU and the kept events are gathered on rank 0.  Returns
+    (per-frame keypoint list of the whole clip, (fps, width, height)) on rank
+    0 and (None, meta) elsewhere.  `device`: this rank's GPU (default: LOCAL_RANK,
+    else the current device); the RCCL exchange buffers live on it."""
+    from .detect import EventDetector, hawkeye_blob_params
+    alone = not dist.is_initialized()       # a single process: no exchange
+    world = 1 if alone else dist.get_world_size(group)
+    rank = 0 if alone else dist.get_rank(group)
+    if device is None:
+        device = default_device()
+    src = make_source()
+    fcount = src.frame_count_estimate
+    first, keep, end = segment_bounds(fcount, world, warmup)[rank]
+    det = detector if detector is not None else EventDetector(
+        src.width, src.height, blob_params=hawkeye_blob_params(src.height),
+        chunk=chunk, device=device)
+    try:
+        det.mog.reset()
+        per_frame = detect_segment(src, det, first, keep, end, chunk=chunk)
+    finally:
+        if detector is None:
+            det.close()
+    meta = (src.fps, src.width, src.height)
+    src.close()
+    if alone:
+        return per_frame, meta
+    where = torch.device('cuda', device) \
+        if dist.get_backend(group) == 'nccl' else 'cpu'
+    rec = gather_events(pack_events(per_frame, keep), device=where,
+                        group=group)
+    if rank != 0:
+        return None, meta
+    return unpack_events(rec, fcount), meta
+
+
+def scan_time_segmented(make_source, warmup=400, device=None, group=None,
                         callback=None):
     """Steps 1-4 of one clip over all ranks of `group`: segmented step 2,
     event gather, steps 3-4 on rank 0.  Returns the notes dict on rank 0 (the
     same keys VideoScanner.process(steps=(1, 4)) leaves) and None elsewhere.
-    `make_source()` -> a frame source with seek()."""
-    from .detect import EventDetector, hawkeye_blob_params
+    `make_source()` -> a frame source with seek().  Every rank must name its
+    own GPU: `device`, else LOCAL_RANK, else torch's current device."""
     from .tracker import VideoScanner
     from .types import Balltag
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    src = make_source()
-    fcount = src.frame_count_estimate
-    first, keep, end = segment_bounds(fcount, world, warmup)[rank]
-    det = EventDetector(src.width, src.height,
-                        blob_params=hawkeye_blob_params(src.height),
-                        device=device)
-    try:
-        per_frame = detect_segment(src, det, first, keep, end)
-    finally:
-        det.close()
-    rec = gather_events(pack_events(per_frame, keep), group=group)
-    meta = (src.fps, src.width, src.height)
-    src.close()
-    if rank != 0:
+    if device is None:
+        device = default_device()
+    events, meta = detect_time_segmented(make_source, warmup=warmup,
+                                         device=device, group=group)
+    if events is None:
         return None
-
-    events = unpack_events(rec, fcount)
+    fcount = len(events)
     sc = VideoScanner('time-segmented clip', device=device)
     notes = sc.notes
     notes['fps'], notes['frame_width'], notes['frame_height'] = meta

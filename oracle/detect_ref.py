@@ -146,3 +146,39 @@ def blob_detect(img, params, cap=65536):
         raise MemoryError
     assert n <= cap
     return out[:n].copy()
+
+
+def detect_clip(frames, params, threads=1, block=64):
+    """Step-2 events of a clip held on the host (uint8 [T][H][W][3]): MOG then
+    the blob detector, frame by frame.  With threads > 1 the work is spread the
+    way OpenCV spreads it: the MOG update over bands of rows (MOGInvoker under
+    parallel_for_, bgfg_gaussmix.cpp; pixels are independent, so the masks are
+    the single-thread ones bit for bit), and the per-frame blob detection over
+    frames.  ctypes drops the GIL inside the C calls, so plain Python threads
+    do.  Returns a list of float32 [n][3] arrays."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    T, H, W = frames.shape[:3]
+    if threads <= 1:
+        mog = Mog(W, H)
+        return [blob_detect(mog.apply(f), params) for f in frames]
+    from concurrent.futures import ThreadPoolExecutor
+    bands = min(threads, H)
+    edges = [(H * b) // bands for b in range(bands + 1)]
+    mogs = [Mog(W, edges[b + 1] - edges[b]) for b in range(bands)]
+    masks = np.empty((min(block, T), H, W), np.uint8)
+    L = lib()
+
+    def mog_band(b, first, count):
+        r0, r1 = edges[b], edges[b + 1]
+        for t in range(count):
+            L.hkref_mog_apply(mogs[b]._h, frames[first + t, r0:r1].ctypes.data,
+                              W * 3, masks[t, r0:r1].ctypes.data, W)
+
+    out = []
+    with ThreadPoolExecutor(threads) as pool:
+        for first in range(0, T, block):
+            count = min(block, T - first)
+            list(pool.map(lambda b: mog_band(b, first, count), range(bands)))
+            out.extend(pool.map(lambda t: blob_detect(masks[t], params),
+                                range(count)))
+    return out

@@ -256,3 +256,22 @@ def test_against_real_opencv_if_present():
         for k, q in zip(kp, mine):
             assert (np.float32(k.pt[0]), np.float32(k.pt[1]),
                     np.float32(k.size)) == tuple(q)
+
+
+def test_detect_clip_threaded_equals_single_thread():
+    rng = np.random.RandomState(3)
+    T, H, W = 40, 61, 80
+    base = rng.randint(60, 120, size=(H, W, 3))
+    frames = np.empty((T, H, W, 3), np.uint8)
+    for t in range(T):
+        f = base + rng.randint(-6, 7, size=(H, W, 3))
+        cx, cy = 10 + t, 20 + (t * 7) % 30
+        f[max(0, cy - 4):cy + 4, max(0, cx - 4):cx + 4] = 250
+        frames[t] = np.clip(f, 0, 255)
+    bp = D.hawkeye_params(480)
+    one = D.detect_clip(frames, bp, threads=1)
+    many = D.detect_clip(frames, bp, threads=5, block=16)
+    assert len(one) == len(many) == T
+    assert sum(len(k) for k in one) > 0
+    for a, b in zip(one, many):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
