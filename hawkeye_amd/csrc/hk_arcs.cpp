@@ -1461,7 +1461,10 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
     };
 
     // every pair the scan could reach with the arcs as they are now
-    std::vector<int> pairs, lookup;
+    // (pairs are generated by ascending i1, then ascending i2: pair_start[i1]
+    // = first pair of i1, and i2 is found by bisection -- memory stays linear
+    // in the number of candidate pairs however many arcs there are)
+    std::vector<int> pairs, pair_start;
     std::vector<MergeTrial> trials;
     const bool verify = g_self_check.load() != 0;
     {
@@ -1484,12 +1487,26 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
             }
             rc = em_merge_trials(c, stream, good_off, good, pairs, trials);
             if (rc != HK_OK) return rc;
-            lookup.assign(A0 * A0, -1);
+            pair_start.assign(A0 + 1, 0);
             for (size_t q = 0; q < pairs.size() / 2; ++q)
-                lookup[(size_t)pairs[2 * q] * A0 + (size_t)pairs[2 * q + 1]] =
-                    (int)q;
+                ++pair_start[(size_t)pairs[2 * q] + 1];
+            for (size_t k = 0; k < A0; ++k) pair_start[k + 1] += pair_start[k];
         }
     }
+    auto find_trial = [&](size_t o1, size_t o2) -> const MergeTrial * {
+        if (pair_start.empty()) return nullptr;
+        int lo = pair_start[o1], hi = pair_start[o1 + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (pairs[2 * (size_t)mid + 1] < (int)o2)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (lo < pair_start[o1 + 1] && pairs[2 * (size_t)lo + 1] == (int)o2)
+            return &trials[(size_t)lo];
+        return nullptr;
+    };
     std::vector<int> orig(A0);              // position now -> position then
     std::iota(orig.begin(), orig.end(), 0);
     std::vector<char> changed(A0, 0);
@@ -1516,9 +1533,7 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
                 if (!candidate(i1, i2)) continue;
                 const MergeTrial *tr = nullptr;
                 const size_t o1 = (size_t)orig[i1], o2 = (size_t)orig[i2];
-                if (!lookup.empty() && !changed[o1] && !changed[o2] &&
-                    lookup[o1 * A0 + o2] >= 0)
-                    tr = &trials[(size_t)lookup[o1 * A0 + o2]];
+                if (!changed[o1] && !changed[o2]) tr = find_trial(o1, o2);
                 if (tr == nullptr || verify) {
                     host_merge_trial(c, a1, cache[i1], cache[i2], rot,
                                      trial_tags, host_trial);

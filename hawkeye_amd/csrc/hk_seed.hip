@@ -37,6 +37,28 @@
 
 #include "hk_seed.h"
 
+// Build option: `make DEVICE_SEEDS=0` leaves the device side of step 3 out of
+// the library (it is opt-in at run time anyway, HK_STEP3_DEVICE, and the
+// multi-thread host builder is the faster one on every clip measured so
+// far).  seed_open() then reports "does not apply here" and hk_arcs.cpp takes
+// its host path, as it does for a clip the fixed-size device lists cannot hold.
+#ifdef HK_NO_DEVICE_SEEDS
+namespace hk {
+struct SeedDevice {};
+void seed_release_cached() {}
+void seed_close(SeedDevice *) {}
+int seed_open(hk_clip &, const SeedParams &, const std::vector<int> &,
+              const std::vector<int> &, int, SeedDevice **out) {
+    *out = nullptr;
+    return HK_OK;
+}
+int seed_windows(const SeedDevice *) { return 0; }
+int seed_round(SeedDevice *, int, const unsigned char *, SeedRound &) {
+    return HK_ERR_INTERNAL;
+}
+}  // namespace hk
+#else
+
 namespace {
 
 using hk::SeedParams;
@@ -877,3 +899,5 @@ int seed_round(SeedDevice *sd, int index, const unsigned char *done,
 }
 
 }  // namespace hk
+
+#endif  // HK_NO_DEVICE_SEEDS

@@ -204,19 +204,31 @@ class OpenCVSource:
         self.width = int(self._cap.get(cv2.CAP_PROP_FRAME_WIDTH))
         self.height = int(self._cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
         self._reads = 0
+        self._ended = False
+        # failed reads are retried until more reads than this were made.  The
+        # reference compares against notes['frame_count_estimate'] -- the
+        # count of the SOURCE video from step 1, also when a scan video is
+        # read (tracker.py:307, 390): VideoScanner sets it; on its own a
+        # source uses its file's estimate
+        self.read_limit = self.frame_count_estimate
 
-    def read(self, max_frames):
-        # same retry rule as reference tracker.py:382-392: failed reads are
-        # skipped until more reads than the estimated frame count were made
+    def _decode(self, max_frames):
+        """Up to max_frames decoded frames (host arrays): the retry rule of
+        reference tracker.py:382-392."""
         got = []
-        while len(got) < max_frames and self._cap.isOpened():
+        while (len(got) < max_frames and not self._ended and
+               self._cap.isOpened()):
             ok, frame = self._cap.read()
             self._reads += 1
             if not ok:
-                if self._reads > self.frame_count_estimate:
-                    break
+                if self._reads > self.read_limit:
+                    self._ended = True      # the reference's loop ends here
                 continue
             got.append(frame)
+        return got
+
+    def read(self, max_frames):
+        got = self._decode(max_frames)
         if not got:
             return torch.empty((0, self.height, self.width, 3),
                                dtype=torch.uint8, device=self.device)
@@ -226,6 +238,7 @@ class OpenCVSource:
     def seek(self, frame):
         self._cap.set(self._cv2.CAP_PROP_POS_FRAMES, int(frame))
         self._reads = int(frame)
+        self._ended = False
 
     def close(self):
         self._cap.release()

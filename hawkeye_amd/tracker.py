@@ -164,6 +164,8 @@ class VideoScanner:
             src = self._open(scanvideo)
             scan_w, scan_h = src.width, src.height
             self._say(2, 'width = {}, height = {}'.format(scan_w, scan_h))
+        if hasattr(src, 'read_limit'):
+            src.read_limit = frame_est      # reference tracker.py:307, 390
         if (src.width, src.height) != (scan_w, scan_h):
             raise ScannerException(
                 'video is {}x{} but notes say {}x{}'.format(
@@ -403,10 +405,22 @@ class VideoScanner:
         if self.body_detector is not None:
             self._say(1, 'Juggler detection starting...')
             notes['body'] = dict(self.body_detector(self))
+            notes['body_source'] = 'detector'
             self._say(1, 'Juggler detection done: {} frames'.format(
                 len(notes['body'])))
         else:
+            # not the reference's result: say so in the notes and, once per
+            # process, to the caller whatever the verbosity (worker.py runs
+            # at verbosity 0)
             notes['body'] = dict()
+            notes['body_source'] = 'estimated'
+            import warnings
+            warnings.warn(
+                'hawkeye_amd: step 5 ran without a body detector; step 6 '
+                'estimates every body box from the tags, so hand assignment '
+                'and throw/catch results can differ from the reference\'s '
+                'YOLO-backed notes (notes[\'body_source\'] = \'estimated\')',
+                RuntimeWarning, stacklevel=2)
             self._say(1, 'Juggler detection skipped (no body detector): body '
                          'positions will be estimated from the detected '
                          'objects\n')

@@ -17,6 +17,12 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
  *     Functions that only enqueue work say so; the others synchronise the
  *     stream before returning host results.
+ *   - multi-GPU: one process per GPU, every process with its own handles.
+ *     Nothing in this library talks to another GPU.  The exchange step of the
+ *     time-segmented layout (per-rank event lists -> rank 0, 16-byte records
+ *     over RCCL) and the sharding of clips over ranks live above the C ABI,
+ *     in hawkeye_amd/dist.py (torch.distributed); a host in another language
+ *     does that one gather with its own RCCL binding.
  *   - handles are not thread safe; use one host thread per handle (the
  *     reference drives the scanner from a single worker thread,
  *     reference worker.py:718-778).

@@ -207,3 +207,32 @@ def test_device_merge_trials_equal_host_trials():
             nat.check(nat.lib.hk_set_self_check(0))
     assert outcomes[0] == outcomes[1]
     assert len(outcomes[0][3]) < outcomes[0][0]        # mergers happened
+
+
+def test_merge_trials_with_thousands_of_arcs():
+    """A long clip: well over a thousand preliminary arcs.  The merge pass
+    finds a pair's device trial by bisection in the sorted pair list (memory
+    linear in the pairs, not quadratic in the arcs); with the self-check on a
+    wrong look-up would fail the step, and the outcome equals the unchecked
+    run."""
+    from hawkeye_amd import _native as nat
+    frames = 16000
+    scene = synth.JugglingScene(1920, 1080, 60.0, 9, frames, 811)
+    meas = synth.make_tags(scene, 812, clutter_per_frame=10.0)
+    outcomes = []
+    for check in (1, 0):
+        nat.check(nat.lib.hk_set_self_check(check))
+        try:
+            clip, _ = make_clip(meas, 1920, 1080, 60.0, frames)
+            clip.build_initial_arcs()
+            n3 = len(clip.arcs()[0])
+            clip.em_optimize()
+            params, ids, tags = clip.arcs()
+            outcomes.append((n3, params.tobytes(), ids.tobytes()))
+            clip.close()
+        finally:
+            nat.check(nat.lib.hk_set_self_check(0))
+    print('preliminary arcs:', outcomes[0][0], 'after EM:',
+          len(outcomes[0][2]) // 8)
+    assert outcomes[0][0] > 1000
+    assert outcomes[0] == outcomes[1]
