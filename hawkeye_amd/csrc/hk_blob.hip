@@ -53,7 +53,7 @@
 namespace {
 
 constexpr int MAXPTS = 256;             // hard cap on a traced contour
-constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_WORDS = 4;
+constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_NTMP = 3, CTR_WORDS = 4;
 constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
 constexpr unsigned BAND_CAP0 = 512;     // candidates per (frame, band, block) to
                                         // start with; grown on demand
@@ -80,6 +80,9 @@ struct BlobRec {
     uint32_t key;           // (y << 16) | x where the raster scan finds it
     int32_t is_hole;
     int32_t npts;
+    int32_t pts_at;         // >= 0: slot of the trace's point list in the
+                            // first-pass buffer; -1: pts[own slot]
+    int32_t pad_;
     long long a00, a10, a01;
     double cx, cy;
     double d2lo, d2hi;      // middle order statistics of squared distances
@@ -135,6 +138,55 @@ __device__ __forceinline__ unsigned row_bit(const uint8_t *row, int x, int W) {
     return (row != nullptr && x >= 0 && x < W) ? (unsigned)(row[x] >> 7) : 0u;
 }
 
+// Candidates that cannot be border starts, found without tracing.  OpenCV
+// starts a border at the first transition of that border in raster order
+// (every pixel of a followed border is marked, contours.cpp), so:
+//  * an outer candidate (first pixel of a run of foreground pixels in its
+//    row, nothing above its own three neighbours) is not a start if ANY pixel
+//    of the run touches a foreground pixel of the row above: the component
+//    has an earlier pixel, and whichever border the candidate lies on was
+//    followed from there;
+//  * a hole candidate (first pixel of a run of background pixels, foreground
+//    to its left and above it) is not a start if any pixel of the run has a
+//    background pixel above it: that pixel belongs to the same background
+//    region and the border had a transition in the row above.  (This is what
+//    the lower-right side of every blob produces: ~4 such candidates per blob,
+//    each of which the tracer used to follow half-way round the blob.)
+// `row` / `up`: bit j = pixel (candidate column - i + j) of the candidate's
+// row / the row above, `avail` bits of them known (pixels beyond the image
+// count as background and may be included); a run that leaves the known bits
+// undecided keeps its candidate.  Removes only candidates whose trace would
+// have been discarded, so results do not change.
+__device__ __forceinline__ void prune_candidates(unsigned &outer,
+                                                 unsigned &hole,
+                                                 unsigned long long row,
+                                                 unsigned long long up,
+                                                 int avail) {
+    unsigned o = outer, h = hole;
+    while (o) {
+        const int i = __ffs(o) - 1;
+        o &= o - 1;
+        const unsigned long long v = ~row >> i;
+        int len = v ? __ffsll((long long)v) - 1 : 64;
+        const int left = avail - i;
+        if (len > left) len = left;
+        const int span = len + 1 > left ? left : len + 1;
+        const unsigned long long m =
+            span >= 64 ? ~0ull : (1ull << span) - 1ull;
+        if ((up >> i) & m) outer &= ~(1u << i);
+    }
+    while (h) {
+        const int i = __ffs(h) - 1;
+        h &= h - 1;
+        const unsigned long long v = row >> i;
+        int len = v ? __ffsll((long long)v) - 1 : 64;
+        const int left = avail - i;
+        if (len > left) len = left;
+        const unsigned long long m = len >= 64 ? ~0ull : (1ull << len) - 1ull;
+        if (~(up >> i) & m) hole &= ~(1u << i);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2
 // ---------------------------------------------------------------------------
@@ -172,6 +224,10 @@ __global__ __launch_bounds__(256) void blob_scan_k(
                      ~(up18 >> 2) & valid;
     unsigned hole = ~(cur17 >> 1) & cur17 & (up18 >> 1) & valid;
     if (nonbinary) atomicOr(&ctr[CTR_FLAGS], FLAG_NONBINARY);
+    // (this lane knows its 16 pixels and pixel x0 + 16 of the row above)
+    if (outer | hole)
+        prune_candidates(outer, hole, cur17 >> 1, up18 >> 1,
+                         x0 + 16 >= W ? 64 : 16);
 
     // candidates go to the list of their (frame, band of rows, block of
     // columns); few 16-pixel segments hold any, so one atomic per such
@@ -294,8 +350,21 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
             const unsigned w = (cur << 1) | left31;
             const unsigned nw = (n << 1) | n_left31;
             const unsigned ne = (n >> 1) | (n_right0 << 31);
-            const unsigned outer = cur & ~w & ~n & ~nw & ~ne;
-            const unsigned hole = ~cur & w & n;
+            unsigned outer = cur & ~w & ~n & ~nw & ~ne;
+            unsigned hole = ~cur & w & n;
+            if (outer | hole) {     // few rows of few tiles: the words to the
+                                    // right of this row and of the one above
+                const unsigned cur_r =
+                    spread16(plane_row(rt.x, rt.y, r)) |
+                    (spread16(plane_row(rt.z, rt.w, r)) << 1);
+                const unsigned n_r =
+                    r == 0 ? spread16(ur.y >> 16) | (spread16(ur.w >> 16) << 1)
+                           : spread16(plane_row(rt.x, rt.y, r - 1)) |
+                                 (spread16(plane_row(rt.z, rt.w, r - 1)) << 1);
+                prune_candidates(outer, hole,
+                                 cur | ((unsigned long long)cur_r << 32),
+                                 n | ((unsigned long long)n_r << 32), 64);
+            }
             emit_candidates(outer, hole, f, ty * 4 + r, tx * 32, cands, ctr,
                             band_rows, nbands, band_cap, ncols);
             n = cur;
@@ -446,12 +515,130 @@ __device__ Trace follow_border(const Image &img, int x0, int y0, bool hole,
     return t;
 }
 
+// ---------------------------------------------------------------------------
+// The same border following, written for the tracing kernel's LDS window and
+// for as few instructions per step as possible (a border is a chain of
+// dependent steps on one lane: its length times the instructions of a step is
+// what the kernel's duration is made of).
+//  * one LDS address per step, three ds_read2_b32 off it, three alignbits;
+//  * positions relative to the start, packed (Y + 256) << 16 | (X + 256): the
+//    closing test is two compares, "before the start in raster order" (outer)
+//    / "above row y0 - 1" (hole) / "too far below" one unsigned range test;
+//  * Green sums in 32 bits on the relative coordinates (|X|, |Y| <= 128, at
+//    most 256 steps) and moved to image coordinates at the end with the exact
+//    identities  a00 = a00',  a10 = a10' + 3 x0 a00',  a01 = a01' + 3 y0 a00'
+//    (closed borders: sum dx = sum dy = 0, sum dx (X3 + X4) = 0,
+//    sum dy (X3 + X4) = a00', sum dx (Y3 + Y4) = -a00');
+//  * the points are written while tracing (into a first-pass slot), so a
+//    border that passes the filters is not followed a second time;
+//  * one exit per iteration.
+// Same decisions and same sums as follow_border(), which stays as the
+// reference form (and as the fallback when the first-pass slots run out).
+struct LeanTrace {
+    int a00, a10, a01, nd, npts;
+    bool valid;
+};
+
+__device__ __forceinline__ unsigned window_ring(const uint32_t *lds, int U,
+                                                int YR) {
+    // U = bit offset of pixel x - 1 from the window's first bit, YR = row of
+    // the window that holds image row y
+    const uint32_t *q = lds + (YR - 1) * WIN_WORDS + (U >> 5);
+    const unsigned u = __builtin_amdgcn_alignbit(q[1], q[0], U);
+    const unsigned m =
+        __builtin_amdgcn_alignbit(q[WIN_WORDS + 1], q[WIN_WORDS], U);
+    const unsigned d =
+        __builtin_amdgcn_alignbit(q[2 * WIN_WORDS + 1], q[2 * WIN_WORDS], U);
+    // E NE N NW W SW S SE = m2 u2 u1 u0 m0 d0 d1 d2
+    const unsigned urev = __builtin_bitreverse32(u) >> 29;
+    return ((m >> 2) & 1u) | (urev << 1) | ((m & 1u) << 4) | ((d & 7u) << 5);
+}
+
+template <bool HOLES>
+__device__ __forceinline__ LeanTrace trace_window(
+    const uint32_t *lds, int U0, int YR0, int x0, int y0, bool hole,
+    int max_pts, uint32_t *__restrict__ out) {
+    LeanTrace t{0, 0, 0, 0, 0, false};
+    const unsigned PK0 = (256u << 16) | 256u;
+    const unsigned absk = (((unsigned)y0 << 16) | (unsigned)x0) - PK0;
+    unsigned nb = window_ring(lds, U0, YR0);
+    if (nb == 0u) {                     // single pixel domain
+        if (out) out[0] = PK0 + absk;
+        t.npts = 1;
+        t.valid = !hole;
+        return t;
+    }
+    const int s0 = (HOLES && hole) ? 0 : 4;
+    // first neighbour clockwise from s0: directions s0-1, s0-2, ... = the
+    // highest set bit of the ring rotated so that direction s0 + k is bit k
+    const unsigned r0 = ((nb | (nb << 8)) >> s0) & 0xFFu;
+    int s = (s0 + (31 - __clz((int)r0))) & 7;
+    const int rx = x0 + 1;
+    if (HOLES && hole) {    // background pixels examined: directions s+1 .. 7
+        const unsigned seen = (0xFFu << (s + 1)) & 0xFFu;
+        if (before_ring(x0, y0, rx, y0) & seen) return t;
+    }
+    const unsigned PK1 = PK0 + (unsigned)(dir_dy(s) * 65536 + dir_dx(s));
+    const int half = max_pts / 2;
+    // positions a trace may be at: LO <= packed < HI, |X| <= half
+    const unsigned LO = (HOLES && hole) ? (255u << 16) : PK0;
+    const unsigned SPAN = ((256u + (unsigned)half + 1u) << 16) - LO;
+
+    int X = 0, Y = 0, npts = 0, nd = 0, a00 = 0, a10 = 0, a01 = 0;
+    unsigned pk3 = PK0;
+    bool valid = false;
+    for (;;) {
+        // sweep counter-clockwise from s + 1 to the next foreground pixel
+        const int first = (s + 1) & 7;
+        const unsigned rot = ((nb | (nb << 8)) >> first) & 0xFFu;
+        const int skip = __ffs((int)rot) - 1;           // rot != 0 always
+        bool bad = npts >= max_pts;
+        if (HOLES) {        // background pixels examined: first .. first+skip-1
+            const unsigned run = (1u << skip) - 1u;
+            const unsigned seen =
+                ((run << first) | (run << first >> 8)) & 0xFFu;
+            bad |= hole && (before_ring(x0 + X, y0 + Y, rx, y0) & seen) != 0u;
+        }
+        s = (first + skip) & 7;
+        if (out && !bad) out[npts] = pk3 + absk;
+        ++npts;
+        nd += s & 1;
+        const int dx = dir_dx(s), dy = dir_dy(s);
+        const int dxy = __mul24(X, dy) - __mul24(dx, Y);
+        a00 += dxy;
+        a10 += __mul24(dxy, 2 * X + dx);
+        a01 += __mul24(dxy, 2 * Y + dy);
+        const unsigned pk4 = pk3 + (unsigned)(dy * 65536 + dx);
+        const bool closed = pk4 == PK0 && pk3 == PK1;
+        X += dx;
+        Y += dy;
+        pk3 = pk4;
+        // an outer border that reaches a pixel before its start, a hole
+        // border above row y0 - 1, any border too far below or beside its
+        // start: given up before the neighbourhood there is read
+        const bool away = pk3 - LO >= SPAN ||
+                          (unsigned)(X + half) > 2u * (unsigned)half;
+        valid = closed && !bad;
+        if (bad || closed || away) break;
+        s = (s + 4) & 7;
+        nb = window_ring(lds, U0 + X, YR0 + Y);
+    }
+    t.a00 = a00;
+    t.a10 = a10;
+    t.a01 = a01;
+    t.nd = nd;
+    t.npts = npts;
+    t.valid = valid;
+    return t;
+}
+
 __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     const uint32_t *__restrict__ bits, int words_per_row, int W,
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
     ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm,
-    unsigned band_cap, int ncols) {
+    unsigned band_cap, int ncols, uint32_t *__restrict__ tmp_pts,
+    unsigned cap_tmp) {
     extern __shared__ uint32_t band_lds[];
     const unsigned bucket = blockIdx.x;
     unsigned n = ctr[CTR_WORDS + bucket];
@@ -479,14 +666,37 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     __syncthreads();
     const BandImg img{band_lds, w0, row0, fbits, words_per_row, W, H};
 
-    for (unsigned i = threadIdx.x; i < n; i += TRACE_THREADS) {
-        const Cand c = cands[(size_t)bucket * band_cap + i];
+    // first-pass point lists: one slot per candidate of this workgroup
+    unsigned tmp_base = 0;
+    if (threadIdx.x == 0) tmp_base = atomicAdd(&ctr[CTR_NTMP], n);
+    tmp_base = __shfl(tmp_base, 0);
+
+    for (unsigned i0 = 0; i0 < n; i0 += TRACE_THREADS) {
+        const unsigned i = i0 + threadIdx.x;
+        const bool have = i < n;
+        const Cand c = have ? cands[(size_t)bucket * band_cap + i]
+                            : Cand{0u, 0u};
         const int x0 = (int)(c.pos & 0xFFFFu), y0 = (int)(c.pos >> 16);
         const bool hole = (c.fh & 1u) != 0u;
-
-        const Trace t = follow_border<false>(img, x0, y0, hole, prm.max_pts,
-                                             nullptr);
-        if (!t.valid) continue;
+        const bool wave_holes = __any(have && hole) != 0;   // wave-uniform
+        if (!have) continue;
+        const unsigned tslot = tmp_base + i;
+        uint32_t *out = tslot < cap_tmp ? tmp_pts + (size_t)tslot * MAXPTS
+                                        : nullptr;
+        const int U0 = x0 - 1 + 32 * (1 - w0), YR0 = y0 - row0;
+        const LeanTrace lt =
+            wave_holes ? trace_window<true>(band_lds, U0, YR0, x0, y0, hole,
+                                            prm.max_pts, out)
+                       : trace_window<false>(band_lds, U0, YR0, x0, y0, false,
+                                             prm.max_pts, out);
+        if (!lt.valid) continue;
+        Trace t;
+        t.a00 = lt.a00;
+        t.a10 = (long long)lt.a10 + 3LL * x0 * lt.a00;
+        t.a01 = (long long)lt.a01 + 3LL * y0 * lt.a00;
+        t.nd = lt.nd;
+        t.ns = lt.npts - lt.nd;
+        t.npts = lt.npts;
 
         // contourMoments(): m00, m10, m01 from the Green sums
         double m00 = 0.0, m10 = 0.0, m01 = 0.0;
@@ -523,6 +733,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
         r.key = ((unsigned)y0 << 16) | (unsigned)(hole ? x0 + 1 : x0);
         r.is_hole = hole ? 1 : 0;
         r.npts = t.npts;
+        r.pts_at = out ? (int)tslot : -1;
+        r.pad_ = 0;
         r.a00 = t.a00;
         r.a10 = t.a10;
         r.a01 = t.a01;
@@ -530,8 +742,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
         r.cy = cy;
         r.d2lo = r.d2hi = 0.0;
         recs[slot] = r;
-        (void)follow_border<true>(img, x0, y0, hole, prm.max_pts,
-                                  pts + (size_t)slot * MAXPTS);
+        if (!out)       // no first-pass slot was left: follow it once more
+            (void)follow_border<true>(img, x0, y0, hole, prm.max_pts,
+                                      pts + (size_t)slot * MAXPTS);
     }
 }
 
@@ -540,7 +753,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void blob_radius_k(
     const unsigned *__restrict__ ctr, unsigned cap_blob,
-    BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts) {
+    BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts,
+    const ushort2 *__restrict__ tmp_pts) {
     __shared__ double d2[MAXPTS];
     unsigned n = ctr[CTR_NBLOB];
     if (n > cap_blob) n = cap_blob;
@@ -548,8 +762,11 @@ __global__ __launch_bounds__(64) void blob_radius_k(
     for (unsigned slot = blockIdx.x; slot < n; slot += gridDim.x) {
         const int m = recs[slot].npts;
         const double cx = recs[slot].cx, cy = recs[slot].cy;
+        const int at = recs[slot].pts_at;
+        const ushort2 *src = at >= 0 ? tmp_pts + (size_t)at * MAXPTS
+                                     : pts + (size_t)slot * MAXPTS;
         for (int i = lane; i < m; i += 64) {
-            const ushort2 p = pts[(size_t)slot * MAXPTS + i];
+            const ushort2 p = src[i];
             const double ddx = cx - (double)p.x;
             const double ddy = cy - (double)p.y;
             d2[i] = ddx * ddx + ddy * ddy;
@@ -697,6 +914,8 @@ struct hk_blob {
     unsigned *ctr = nullptr;
     BlobRec *recs = nullptr;
     ushort2 *pts = nullptr;
+    uint32_t *tmp_pts = nullptr;        // first-pass point lists, cap_tmp slots
+    unsigned cap_tmp = 0;
     uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
     int words_per_row = 0;              // (W + 31) / 32 + 2
     unsigned *h_ctr = nullptr;          // pinned
@@ -744,6 +963,7 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->ctr);
     (void)hipFree(b->recs);
     (void)hipFree(b->pts);
+    (void)hipFree(b->tmp_pts);
     (void)hipFree(b->bits);
     (void)hipFree(b->tiles);
     (void)hipHostFree(b->h_ctr);
@@ -839,6 +1059,13 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->pts,
                       sizeof(ushort2) * MAXPTS * (size_t)b->cap_blob);
+    // a first-pass point list per candidate traced: 256 per frame is a few
+    // times what noisy 1080p frames produce after pruning; when they run out
+    // a border that passes the filters is followed a second time instead
+    b->cap_tmp = (unsigned)max_frames * 256u;
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->tmp_pts,
+                      sizeof(uint32_t) * MAXPTS * (size_t)b->cap_tmp);
     const size_t bit_bytes = sizeof(uint32_t) * (size_t)max_frames *
                              (height + 2) * b->words_per_row;
     if (e == hipSuccess) e = hipMalloc((void **)&b->bits, bit_bytes);
@@ -898,10 +1125,12 @@ static int launch_batch(hk_blob *b, int nframes) {
                        b->trace_lds,
                        s, b->bits, b->words_per_row, b->width, b->height,
                        b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
-                       b->pts, b->cap_blob, b->dev, b->band_cap, b->ncols);
+                       b->pts, b->cap_blob, b->dev, b->band_cap, b->ncols,
+                       b->tmp_pts, b->cap_tmp);
     HK_LAUNCH_CHECK("blob_trace_k");
     hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
-                       b->cap_blob, b->recs, b->pts);
+                       b->cap_blob, b->recs, b->pts,
+                       (const ushort2 *)b->tmp_pts);
     HK_LAUNCH_CHECK("blob_radius_k");
     HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
                           hipMemcpyDeviceToHost, s));
