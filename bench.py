@@ -325,7 +325,25 @@ def run_clips(args, world, rank, local):
         builders = args.builders
     if args.host_threads is not None:
         host_threads = args.host_threads
+    # Untimed pre-roll of the pipelined path itself (the W warm-up scans above
+    # run one clip at a time and leave the builder threads' streams, the
+    # pooled EM workspaces and the chip's clocks cold): batches of W clips
+    # until `--preroll-seconds` have passed.  A fresh box gives 5-10 % less in
+    # its first second of pipelined work than afterwards (tools/probe_warm.py).
+    preroll_t0 = time.perf_counter()
+    preroll_clips = 0
+    while args.warmup > 0 and \
+            time.perf_counter() - preroll_t0 < args.preroll_seconds:
+        n = max(2, args.warmup)
+        for _ in scanner.scan_many((frames for _ in range(n)),
+                                   host_threads=host_threads,
+                                   builders=builders, count=n):
+            preroll_clips += 1
+    preroll_s = time.perf_counter() - preroll_t0
+    # (every 8th launch is bracketed by timing events: bracketing all of them
+    # slowed the timed region by 15 %, tools/probe_batch_stages.py)
     scanner.detector.mog_timing = []
+    scanner.detector.mog_timing_every = args.time_every
     stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
     barrier()
     t0 = time.perf_counter()
@@ -337,7 +355,9 @@ def run_clips(args, world, rank, local):
     barrier()
     elapsed = time.perf_counter() - t0
     launch_ms, launch_frames = launch_times(scanner.detector.mog_timing)
+    launches_timed = len(scanner.detector.mog_timing)
     scanner.detector.mog_timing = None
+    scanner.detector.mog_timing_every = 1
 
     # the same launches with nothing else on the GPU (no blob kernels of the
     # previous chunk in their way): the kernel's own duration, which is what
@@ -387,6 +407,9 @@ def run_clips(args, world, rank, local):
                    'detect_chunk_frames': CHUNK},
         'host_cores_per_rank': host_core_share(),
         'builders': builders, 'step3_threads_per_clip': host_threads,
+        'untimed_preroll': {'seconds': round(preroll_s, 2),
+                            'pipelined_clips': preroll_clips,
+                            'single_clip_scans': args.warmup + 3},
         'pipeline': 'detection of the passes ahead (GPU) beside steps 3-4 '
                     'of the passes before (one host thread per pass); every '
                     'pass does all the work',
@@ -403,6 +426,7 @@ def run_clips(args, world, rank, local):
         'roofline': mog_roofline(launch_ms, alone_ms, launch_frames, px,
                                  None if args.frames else 'clip'),
     }
+    out['roofline']['launches_timed'] = launches_timed
 
     if world == 1 and args.host_frames > 0:
         out['pcie_inclusive'] = from_host_rate(scanner, spec, frames,
@@ -512,6 +536,7 @@ def run_segments(args, world, rank, local):
     for _ in range(args.warmup):
         one_pass()
     det.mog_timing = []
+    det.mog_timing_every = args.time_every
     stage_s = {'detect+gather': 0.0, 'step3': 0.0, 'step4': 0.0}
     barrier()
     t0 = time.perf_counter()
@@ -524,6 +549,7 @@ def run_segments(args, world, rank, local):
     elapsed = time.perf_counter() - t0
     launch_ms, launch_frames = launch_times(det.mog_timing)
     det.mog_timing = None
+    det.mog_timing_every = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -611,6 +637,12 @@ def main():
                     help='shorter clip (debugging only; invalidates value)')
     ap.add_argument('--segment-warmup', type=int, default=400,
                     help='frames a segment starts early (--layout segments)')
+    ap.add_argument('--preroll-seconds', type=float, default=2.0,
+                    help='untimed pipelined batches before the timed region '
+                         '(--layout clips; 0 = none)')
+    ap.add_argument('--time-every', type=int, default=8,
+                    help='bracket every n-th MOG launch of the timed region '
+                         'with timing events (roofline.launch_ms)')
     ap.add_argument('--cpu-sample', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=None,

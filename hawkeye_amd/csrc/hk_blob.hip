@@ -67,8 +67,13 @@ constexpr int TRACE_THREADS = 64;
 // plus COL_MARGIN words (128 pixels) on either side.  A closed border of at
 // most max_pts <= 256 points stays within max_pts / 2 pixels of its start in
 // every direction, and a trace that goes further is given up.
+// The window starts at a multiple of four words (rows of the 1-bit image are
+// padded to a multiple of four words, so that the window is filled with
+// 16-byte loads): 5 words of margin on the left, 7 on the right.
 constexpr int COL_WORDS = 8, COL_MARGIN = 4;
-constexpr int WIN_WORDS = COL_WORDS + 2 * COL_MARGIN;
+constexpr int WIN_WORDS = 20;
+static_assert(WIN_WORDS % 4 == 0 && WIN_WORDS >= COL_WORDS + 2 * COL_MARGIN + 2,
+              "window: block + margins, whole 16-byte groups");
 
 struct Cand {
     uint32_t pos;           // (y << 16) | x of the start (foreground) pixel
@@ -648,20 +653,51 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     const unsigned fb = bucket / (unsigned)ncols;
     const int frame = (int)(fb / (unsigned)nbands);
     const int band = (int)(fb % (unsigned)nbands);
-    // image rows band*band_rows - 2 .. + band_rows + max_pts/2 + 1 (a border
-    // that starts on the band's first row y0 steps up to row y0 - 1 at most,
-    // and the neighbourhood read there reaches row y0 - 2), words w0 .. w0 +
-    // WIN_WORDS - 1 of the padded rows; zeros outside the padded frame
-    const int row0 = band * band_rows - 2;
-    int nrows = band_rows + prm.max_pts / 2 + 4;
+    // The window: image rows ymin - 2 .. ymax + max_pts/2 + 2 for the first
+    // and last start row among the candidates (a border that starts on row y0
+    // steps up to row y0 - 1 at most, and the neighbourhood read there
+    // reaches row y0 - 2; it is given up max_pts/2 rows below y0), words w0 ..
+    // w0 + WIN_WORDS - 1 of the padded rows; zeros outside the padded frame.
+    int ymin = 0x7FFFFFFF, ymax = 0;
+    for (unsigned i = threadIdx.x; i < n; i += TRACE_THREADS) {
+        const int y = (int)(cands[(size_t)bucket * band_cap + i].pos >> 16);
+        ymin = y < ymin ? y : ymin;
+        ymax = y > ymax ? y : ymax;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const int a = __shfl_xor(ymin, d), c = __shfl_xor(ymax, d);
+        ymin = a < ymin ? a : ymin;
+        ymax = c > ymax ? c : ymax;
+    }
+    const int row0 = ymin - 2;
+    int nrows = ymax - ymin + prm.max_pts / 2 + 5;
     if (row0 + nrows > H + 1) nrows = H + 1 - row0;
-    const int w0 = 1 + col * COL_WORDS - COL_MARGIN;
+    const int w0 = col * COL_WORDS - 4;
     const uint32_t *fbits = bits + (long)frame * (H + 2) * words_per_row;
-    for (int i = threadIdx.x; i < nrows * WIN_WORDS; i += TRACE_THREADS) {
-        const int r = i / WIN_WORDS, w = w0 + (i - r * WIN_WORDS);
-        const int prow = row0 + r + 1;          // row of the padded frame
-        band_lds[i] = prow >= 0 && prow < H + 2 && w >= 0 && w < words_per_row
-                          ? fbits[(long)prow * words_per_row + w] : 0u;
+    {
+        // 16-byte groups, eight loads in flight per lane before the stores
+        constexpr int G = WIN_WORDS / 4;
+        const int total = nrows * G;
+        uint4 *lds4 = reinterpret_cast<uint4 *>(band_lds);
+        for (int k0 = 0; k0 < total; k0 += 8 * TRACE_THREADS) {
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * TRACE_THREADS + (int)threadIdx.x;
+                const int r = k / G, w = w0 + 4 * (k - r * G);
+                const int prow = row0 + r + 1;      // row of the padded frame
+                v[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (k < total && prow >= 0 && prow < H + 2 && w >= 0 &&
+                    w < words_per_row)
+                    v[j] = *reinterpret_cast<const uint4 *>(
+                        fbits + (long)prow * words_per_row + w);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * TRACE_THREADS + (int)threadIdx.x;
+                if (k < total) lds4[k] = v[j];
+            }
+        }
     }
     __syncthreads();
     const BandImg img{band_lds, w0, row0, fbits, words_per_row, W, H};
@@ -917,7 +953,7 @@ struct hk_blob {
     uint32_t *tmp_pts = nullptr;        // first-pass point lists, cap_tmp slots
     unsigned cap_tmp = 0;
     uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
-    int words_per_row = 0;              // (W + 31) / 32 + 2
+    int words_per_row = 0;              // (W + 31) / 32 + 2, rounded up to 4
     unsigned *h_ctr = nullptr;          // pinned
     BlobRec *h_recs = nullptr;          // pinned, cap_blob entries
     hipEvent_t done = nullptr;
@@ -1031,15 +1067,16 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
          t += params->thresholdStep)
         ++b->n_thresholds;
     // K3 holds band_rows + max_pts/2 + 4 rows of a WIN_WORDS-wide window of
-    // the 1-bit image in LDS (11 KB for Hawkeye's parameters)
-    b->words_per_row = (width + 31) / 32 + 2;
+    // the 1-bit image in LDS at most (14 KB for Hawkeye's parameters; fewer
+    // rows when the candidates of a workgroup start close together)
+    b->words_per_row = ((width + 31) / 32 + 2 + 3) / 4 * 4;
     {
         const int extra = max_pts / 2 + 4;
         b->band_rows = std::min(64, height);
         b->nbands = (height + b->band_rows - 1) / b->band_rows;
         b->ncols = ((width + 31) / 32 + COL_WORDS - 1) / COL_WORDS;
         // (+1 word: the 64-bit read of a row's last word looks one ahead)
-        b->trace_lds = (size_t)4 * (WIN_WORDS * (b->band_rows + extra) + 1);
+        b->trace_lds = (size_t)4 * (WIN_WORDS * (b->band_rows + extra) + 4);
     }
     const size_t nbuckets = (size_t)max_frames * b->nbands * b->ncols;
     b->cap_blob = (unsigned)max_frames * 128u;
@@ -1268,6 +1305,10 @@ static int wait_done(hk_blob *b) {
         const double v = e ? atof(e) : 0.0;
         return v > 0.0 ? v : 60.0;
     }();
+    static const double spin_s = [] {
+        const char *e = getenv("HK_BLOB_SPIN_US");
+        return e ? atof(e) * 1e-6 : 0.0;
+    }();
     using clock = std::chrono::steady_clock;
     const auto t0 = clock::now();
     for (long spins = 0;; ++spins) {
@@ -1279,6 +1320,7 @@ static int wait_done(hk_blob *b) {
         if (spins < 200) continue;              // ~ the first 100 us: spin
         const double waited =
             std::chrono::duration<double>(clock::now() - t0).count();
+        if (waited < spin_s) continue;
         if (waited > limit_s)
             return hk::fail(HK_ERR_HIP,
                             "hk_blob: the batch did not finish within %.0f s "

@@ -283,7 +283,13 @@ class EventDetector:
         self._collected = 0         # chunks whose keypoints were returned
         # set to a list to collect (start, end, frames) event triples of the
         # MOG launches, recorded on the stream they run on
+        # benchmarking: a list to which (start event, end event, frames) of
+        # every mog_timing_every-th MOG launch is appended.  Two timing events
+        # around a launch cost the pipeline about 0.1 ms (the launch no
+        # longer overlaps its neighbours in the queue), so a timed region
+        # samples launches instead of bracketing all of them
         self.mog_timing = None
+        self.mog_timing_every = 1
         self._side = torch.cuda.Stream(device=self.device)
         self._mog_done = [torch.cuda.Event() for _ in range(self.DEPTH)]
 
@@ -307,7 +313,7 @@ class EventDetector:
 
             def run_mog():
                 self.mog.apply_batch(frames, out=masks)
-        if self.mog_timing is None:
+        if self.mog_timing is None or self._next % self.mog_timing_every:
             run_mog()
         else:
             e0 = torch.cuda.Event(enable_timing=True)
