@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhawkeye_hip.so')
+# HK_NATIVE_LIB: another build of the same library (instrumented builds of
+# tools/); never a different implementation -- there is no CPU fallback
+LIB_PATH = os.environ.get('HK_NATIVE_LIB') or \
+    os.path.join(_HERE, 'libhawkeye_hip.so')
 
 
 class NativeError(RuntimeError):
