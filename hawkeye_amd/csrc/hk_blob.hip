@@ -53,7 +53,8 @@
 namespace {
 
 constexpr int MAXPTS = 256;             // hard cap on a traced contour
-constexpr int CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_NTMP = 3, CTR_WORDS = 4;
+constexpr int CTR_NACTIVE = 0, CTR_NBLOB = 1, CTR_FLAGS = 2, CTR_NTMP = 3,
+              CTR_NEXT = 4, CTR_WORDS = 8;
 constexpr unsigned FLAG_NONBINARY = 1u, FLAG_BAND_FULL = 2u;
 constexpr unsigned BAND_CAP0 = 512;     // candidates per (frame, band, block) to
                                         // start with; grown on demand
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void blob_scan_k(
     int H, int nframes, int segs, bool vec, Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, int band_rows, int nbands,
     unsigned short *__restrict__ bits, int words_per_row, unsigned band_cap,
-    int ncols) {
+    int ncols, unsigned *__restrict__ active) {
     const long tid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)nframes * H * segs;
     if (tid >= total) return;
@@ -243,6 +244,8 @@ __global__ __launch_bounds__(256) void blob_scan_k(
         ((unsigned)f * nbands + (unsigned)(y / band_rows)) * ncols +
         (unsigned)(x0 / (32 * COL_WORDS));
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
+    if (at == 0u)       // the bucket's first candidates: list it for tracing
+        active[atomicAdd(&ctr[CTR_NACTIVE], 1u)] = bucket;
     if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
     Cand *list = cands + (size_t)bucket * band_cap;
     while (outer) {
@@ -288,13 +291,16 @@ __device__ __forceinline__ unsigned plane_row(unsigned p01, unsigned p23,
 
 __device__ __forceinline__ void emit_candidates(
     unsigned outer, unsigned hole, int f, int y, int x0, Cand *cands,
-    unsigned *ctr, int band_rows, int nbands, unsigned band_cap, int ncols) {
+    unsigned *ctr, int band_rows, int nbands, unsigned band_cap, int ncols,
+    unsigned *active) {
     const unsigned c = __popc(outer) + __popc(hole);
     if (c == 0) return;
     const unsigned bucket =
         ((unsigned)f * nbands + (unsigned)(y / band_rows)) * ncols +
         (unsigned)(x0 / (32 * COL_WORDS));
     unsigned at = atomicAdd(&ctr[CTR_WORDS + bucket], c);
+    if (at == 0u)       // the bucket's first candidates: list it for tracing
+        active[atomicAdd(&ctr[CTR_NACTIVE], 1u)] = bucket;
     if (at + c > band_cap) atomicOr(&ctr[CTR_FLAGS], FLAG_BAND_FULL);
     Cand *list = cands + (size_t)bucket * band_cap;
     while (outer) {
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
     const uint4 *__restrict__ tiles, int tiles_x, int tiles_y, int nframes,
     int H, uint32_t *__restrict__ bits, int words_per_row,
     Cand *__restrict__ cands, unsigned *__restrict__ ctr, int band_rows,
-    int nbands, unsigned band_cap, int ncols) {
+    int nbands, unsigned band_cap, int ncols, unsigned *__restrict__ active) {
     const long per_frame = (long)tiles_x * tiles_y;
     const long total = (long)nframes * per_frame;
     for (long tid = (long)blockIdx.x * 256 + threadIdx.x; tid < total;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256) void blob_scan_tiles_k(
                                  n | ((unsigned long long)n_r << 32), 64);
             }
             emit_candidates(outer, hole, f, ty * 4 + r, tx * 32, cands, ctr,
-                            band_rows, nbands, band_cap, ncols);
+                            band_rows, nbands, band_cap, ncols, active);
             n = cur;
             n_left31 = left31;
             n_right0 = right0;
@@ -637,22 +643,21 @@ __device__ __forceinline__ LeanTrace trace_window(
     return t;
 }
 
-__global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
+// The candidates of one (frame, band, block of columns).
+__device__ __forceinline__ void trace_bucket(
+    const unsigned bucket, uint32_t *band_lds,
     const uint32_t *__restrict__ bits, int words_per_row, int W,
     int H, int band_rows, int nbands, const Cand *__restrict__ cands,
     unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
-    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm,
+    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams &prm,
     unsigned band_cap, int ncols, uint32_t *__restrict__ tmp_pts,
     unsigned cap_tmp) {
-    extern __shared__ uint32_t band_lds[];
-    const unsigned bucket = blockIdx.x;
     unsigned n = ctr[CTR_WORDS + bucket];
     if (n == 0) return;                     // workgroup-uniform
     if (n > band_cap) n = band_cap;
     const int col = (int)(bucket % (unsigned)ncols);
     const unsigned fb = bucket / (unsigned)ncols;
     const int frame = (int)(fb / (unsigned)nbands);
-    const int band = (int)(fb % (unsigned)nbands);
     // The window: image rows ymin - 2 .. ymax + max_pts/2 + 2 for the first
     // and last start row among the candidates (a border that starts on row y0
     // steps up to row y0 - 1 at most, and the neighbourhood read there
@@ -784,6 +789,32 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
     }
 }
 
+// A fixed number of single-wave workgroups take the buckets that hold
+// candidates (listed by the scan kernel) off a queue until it is empty.  One
+// workgroup per bucket of the batch -- 17 000 per 128 frames at 1080p, two
+// thirds of them empty -- made every one of them wait for a wave slot and
+// 14 KB of LDS among the MOG waves of the next chunk just to find that out.
+__global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
+    const uint32_t *__restrict__ bits, int words_per_row, int W,
+    int H, int band_rows, int nbands, const Cand *__restrict__ cands,
+    unsigned *__restrict__ ctr, BlobRec *__restrict__ recs,
+    ushort2 *__restrict__ pts, unsigned cap_blob, const DevParams prm,
+    unsigned band_cap, int ncols, uint32_t *__restrict__ tmp_pts,
+    unsigned cap_tmp, const unsigned *__restrict__ active) {
+    extern __shared__ uint32_t band_lds[];
+    const unsigned n_active = ctr[CTR_NACTIVE];
+    for (;;) {
+        unsigned at = 0;
+        if (threadIdx.x == 0) at = atomicAdd(&ctr[CTR_NEXT], 1u);
+        at = __shfl(at, 0);
+        if (at >= n_active) break;          // every wave gets here
+        trace_bucket(active[at], band_lds, bits, words_per_row, W, H,
+                     band_rows, nbands, cands, ctr, recs, pts, cap_blob, prm,
+                     band_cap, ncols, tmp_pts, cap_tmp);
+        __syncthreads();                    // before the window is refilled
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K3b
 // ---------------------------------------------------------------------------
@@ -891,34 +922,50 @@ void emit_group(const Center *g, size_t n, std::vector<float> &out) {
 // in the first pass at its own position in the group list.  Only the
 // remaining centres go through the literal replay, among themselves; groups
 // the replay creates after the first pass come last, as in the full loop.
-void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
+void group_keypoints(const Center *cur, size_t n, int n_thresholds,
                      const hk_blob_params &p, std::vector<float> &out) {
-    const size_t n = cur.size();
     if (n == 0 || n_thresholds <= 0) return;
     const double min_dist = p.minDistBetweenBlobs;
-    std::vector<char> linked(n, 0);
+    // (a detection thread calls this for every frame: the scratch vectors
+    // live across calls)
+    static thread_local std::vector<char> linked;
+    linked.assign(n, 0);
     bool any = false;
     for (size_t i = 0; i < n; ++i)
         for (size_t j = i + 1; j < n; ++j) {
             const double ddx = cur[i].x - cur[j].x, ddy = cur[i].y - cur[j].y;
-            const double dist = std::sqrt(ddx * ddx + ddy * ddy);
-            if (!(dist >= min_dist && dist >= cur[i].radius &&
-                  dist >= cur[j].radius)) {
+            const double q = ddx * ddx + ddy * ddy;
+            // "dist >= min_dist, radius i and radius j" with dist = sqrt(q):
+            // decided on the squares unless q is within rounding of the
+            // largest bound's square (sqrt is monotonic, correctly rounded)
+            double m = min_dist;
+            if (cur[i].radius > m) m = cur[i].radius;
+            if (cur[j].radius > m) m = cur[j].radius;
+            const double m2 = m * m;
+            bool apart;
+            if (q > m2 * (1 + 1e-12)) {
+                apart = true;
+            } else if (q < m2 * (1 - 1e-12)) {
+                apart = false;
+            } else {
+                const double dist = std::sqrt(q);
+                apart = dist >= min_dist && dist >= cur[i].radius &&
+                        dist >= cur[j].radius;
+            }
+            if (!apart) {
                 linked[i] = linked[j] = 1;
                 any = true;
             }
         }
     std::vector<std::vector<Center>> groups;
+    size_t first_pass = 0;
     if (any) {
         std::vector<Center> sub;
         for (size_t i = 0; i < n; ++i)
             if (linked[i]) sub.push_back(cur[i]);
+        first_pass = sub.size();
         replay_groups(sub, n_thresholds, p, groups);
     }
-    const size_t first_pass = any ? (size_t)std::count(linked.begin(),
-                                                       linked.end(), 1)
-                                  : 0;
-    std::vector<Center> copies((size_t)n_thresholds);
     size_t next_sub = 0;
     for (size_t i = 0; i < n; ++i) {
         if (linked[i]) {
@@ -926,14 +973,38 @@ void group_keypoints(const std::vector<Center> &cur, int n_thresholds,
             if ((int)g.size() >= p.minRepeatability)
                 emit_group(g.data(), g.size(), out);
         } else if (n_thresholds >= p.minRepeatability) {
-            std::fill(copies.begin(), copies.end(), cur[i]);
-            emit_group(copies.data(), copies.size(), out);
+            // n_thresholds copies of the centre: the same sequential sums
+            double sx = 0, sy = 0, normalizer = 0;
+            for (int k = 0; k < n_thresholds; ++k) {
+                sx += 1.0 * cur[i].x;
+                sy += 1.0 * cur[i].y;
+                normalizer += 1.0;
+            }
+            const double inv = 1. / normalizer;
+            sx *= inv;
+            sy *= inv;
+            out.push_back((float)sx);
+            out.push_back((float)sy);
+            out.push_back((float)(cur[i].radius) * 2.0f);
         }
     }
     for (size_t k = first_pass; k < groups.size(); ++k)
         if ((int)groups[k].size() >= p.minRepeatability)
             emit_group(groups[k].data(), groups[k].size(), out);
 }
+
+// The contours of a batch that passed the filters: centres of all frames,
+// frame f's in [off[f], off[f + 1]), in the order findContours(RETR_LIST)
+// lists them.
+struct Contours {
+    std::vector<Center> centers;
+    std::vector<int> off;
+    void swap(Contours &o) {
+        centers.swap(o.centers);
+        off.swap(o.off);
+    }
+    size_t frames() const { return off.empty() ? 0 : off.size() - 1; }
+};
 
 }  // namespace
 
@@ -952,6 +1023,7 @@ struct hk_blob {
     ushort2 *pts = nullptr;
     uint32_t *tmp_pts = nullptr;        // first-pass point lists, cap_tmp slots
     unsigned cap_tmp = 0;
+    unsigned *active = nullptr;         // buckets that hold candidates
     uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
     int words_per_row = 0;              // (W + 31) / 32 + 2, rounded up to 4
     unsigned *h_ctr = nullptr;          // pinned
@@ -968,7 +1040,7 @@ struct hk_blob {
     std::vector<unsigned> h_counts;     // per-band candidate counts
     // contours of a finished batch whose results did not fit the caller's
     // buffer: handed out by the next hk_blob_finish*() call
-    std::vector<std::vector<Center>> held;
+    Contours held;
     bool has_held = false;
 };
 
@@ -1000,6 +1072,7 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->recs);
     (void)hipFree(b->pts);
     (void)hipFree(b->tmp_pts);
+    (void)hipFree(b->active);
     (void)hipFree(b->bits);
     (void)hipFree(b->tiles);
     (void)hipHostFree(b->h_ctr);
@@ -1099,6 +1172,8 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     // a first-pass point list per candidate traced: 256 per frame is a few
     // times what noisy 1080p frames produce after pruning; when they run out
     // a border that passes the filters is followed a second time instead
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->active, sizeof(unsigned) * nbuckets);
     b->cap_tmp = (unsigned)max_frames * 256u;
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->tmp_pts,
@@ -1137,13 +1212,18 @@ static int launch_batch(hk_blob *b, int nframes) {
         const long total = (long)nframes * tiles_x * tiles_y;
         // few, long-lived workgroups: this runs beside the MOG launch of the
         // next chunk, which leaves wave slots free only now and then
+        static const long scan_grid = [] {
+            const char *e = getenv("HK_BLOB_SCAN_GRID");
+            const int v = e ? atoi(e) : 0;
+            return v > 0 ? (long)v : 2048L;
+        }();
         const unsigned blocks =
-            (unsigned)std::min<long>((total + 255) / 256, 2048);
+            (unsigned)std::min<long>((total + 255) / 256, scan_grid);
         hipLaunchKernelGGL(blob_scan_tiles_k, dim3(blocks), dim3(256), 0, s,
                            (const uint4 *)b->tiles, tiles_x, tiles_y, nframes,
                            b->height, b->bits, b->words_per_row, b->cands,
                            b->ctr, b->band_rows, b->nbands, b->band_cap,
-                           b->ncols);
+                           b->ncols, b->active);
         HK_LAUNCH_CHECK("blob_scan_tiles_k");
     } else {
         const int segs = (b->width + 15) / 16;
@@ -1155,17 +1235,33 @@ static int launch_batch(hk_blob *b, int nframes) {
                            b->width, b->height, nframes, segs, vec, b->cands,
                            b->ctr, b->band_rows, b->nbands,
                            (unsigned short *)b->bits, b->words_per_row,
-                           b->band_cap, b->ncols);
+                           b->band_cap, b->ncols, b->active);
         HK_LAUNCH_CHECK("blob_scan_k");
     }
-    hipLaunchKernelGGL(blob_trace_k, dim3(nbuckets), dim3(TRACE_THREADS),
-                       b->trace_lds,
+    // The grid only bounds how many buckets are traced at a time: two
+    // workgroups per CU of an MI355X.  Measured beside the MOG launches of
+    // the next chunk (detection of the 1080p benchmark clip, ms per clip):
+    // 256: 7.95, 384: 7.71, 512: 7.63, 640: 7.78, 1024: 8.07, 2048: 8.50,
+    // one workgroup per bucket as before: 8.75.
+    static const unsigned trace_grid = [] {
+        const char *e = getenv("HK_BLOB_TRACE_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (unsigned)v : 512u;
+    }();
+    hipLaunchKernelGGL(blob_trace_k,
+                       dim3(nbuckets < trace_grid ? nbuckets : trace_grid),
+                       dim3(TRACE_THREADS), b->trace_lds,
                        s, b->bits, b->words_per_row, b->width, b->height,
                        b->band_rows, b->nbands, b->cands, b->ctr, b->recs,
                        b->pts, b->cap_blob, b->dev, b->band_cap, b->ncols,
-                       b->tmp_pts, b->cap_tmp);
+                       b->tmp_pts, b->cap_tmp, b->active);
     HK_LAUNCH_CHECK("blob_trace_k");
-    hipLaunchKernelGGL(blob_radius_k, dim3(1024), dim3(64), 0, s, b->ctr,
+    static const unsigned radius_grid = [] {
+        const char *e = getenv("HK_BLOB_RADIUS_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (unsigned)v : 1024u;
+    }();
+    hipLaunchKernelGGL(blob_radius_k, dim3(radius_grid), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts,
                        (const ushort2 *)b->tmp_pts);
     HK_LAUNCH_CHECK("blob_radius_k");
@@ -1194,7 +1290,7 @@ extern "C" int hk_blob_enqueue(hk_blob *b, const void *mask_dev,
                         "hk_blob_enqueue: previous batch not finished");
     hk::DeviceGuard guard(b->device);
     b->has_held = false;
-    b->held.clear();
+    b->held = Contours();
     b->stream = (hipStream_t)stream;
     b->masks = (const uint8_t *)mask_dev;
     b->frame_stride = frame_stride;
@@ -1239,7 +1335,7 @@ extern "C" int hk_blob_enqueue_tiles(hk_blob *b, int nframes, void *stream) {
                         "hk_blob_enqueue_tiles: previous batch not finished");
     hk::DeviceGuard guard(b->device);
     b->has_held = false;
-    b->held.clear();
+    b->held = Contours();
     b->stream = (hipStream_t)stream;
     b->masks = nullptr;
     b->frame_stride = b->pitch = 0;
@@ -1336,7 +1432,7 @@ static int wait_done(hk_blob *b) {
 
 // Waits for the batch and returns the surviving contours per frame in the
 // order findContours(RETR_LIST) lists them (reverse discovery order).
-static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
+static int collect(hk_blob *b, Contours &frames) {
     if (!b) return hk::fail(HK_ERR_ARG, "hk_blob_finish: null handle");
     if (!b->pending_frames && b->has_held) {
         frames.swap(b->held);
@@ -1376,22 +1472,43 @@ static int collect(hk_blob *b, std::vector<std::vector<Center>> &frames) {
                               hipMemcpyDeviceToHost, b->stream));
         HK_HIP(hipStreamSynchronize(b->stream));
     }
-    std::vector<const BlobRec *> order(nblob);
-    for (unsigned i = 0; i < nblob; ++i) order[i] = &b->h_recs[i];
-    std::sort(order.begin(), order.end(),
-              [](const BlobRec *p, const BlobRec *q) {
-                  if (p->frame != q->frame) return p->frame < q->frame;
-                  return p->key > q->key;       // last discovered first
-              });
-    frames.assign(nframes, std::vector<Center>());
-    for (const BlobRec *r : order) {
-        if (r->frame < 0 || r->frame >= nframes)
+    // by frame (counting sort), within a frame last discovered first
+    // (descending key; a few dozen per frame)
+    std::vector<int> &off = frames.off;
+    off.assign((size_t)nframes + 1, 0);
+    for (unsigned i = 0; i < nblob; ++i) {
+        const int f = b->h_recs[i].frame;
+        if (f < 0 || f >= nframes)
             return hk::fail(HK_ERR_INTERNAL, "hk_blob: bad frame index");
-        Center c;
-        c.x = r->cx;
-        c.y = r->cy;
-        c.radius = (std::sqrt(r->d2lo) + std::sqrt(r->d2hi)) / 2.;
-        frames[r->frame].push_back(c);
+        ++off[(size_t)f + 1];
+    }
+    for (int f = 0; f < nframes; ++f) off[(size_t)f + 1] += off[(size_t)f];
+    static thread_local std::vector<unsigned> slot, fill;
+    slot.resize(nblob);
+    fill.assign(off.begin(), off.end() - 1);
+    for (unsigned i = 0; i < nblob; ++i)
+        slot[fill[(size_t)b->h_recs[i].frame]++] = i;
+    frames.centers.resize(nblob);
+    for (int f = 0; f < nframes; ++f) {
+        unsigned *lo = slot.data() + off[(size_t)f];
+        unsigned *hi = slot.data() + off[(size_t)f + 1];
+        for (unsigned *p = lo + 1; p < hi; ++p) {       // insertion sort
+            const unsigned v = *p;
+            const uint32_t key = b->h_recs[v].key;
+            unsigned *q = p;
+            while (q > lo && b->h_recs[q[-1]].key < key) {
+                *q = q[-1];
+                --q;
+            }
+            *q = v;
+        }
+        for (unsigned *p = lo; p < hi; ++p) {
+            const BlobRec &r = b->h_recs[*p];
+            Center &c = frames.centers[(size_t)(p - slot.data())];
+            c.x = r.cx;
+            c.y = r.cy;
+            c.radius = (std::sqrt(r.d2lo) + std::sqrt(r.d2hi)) / 2.;
+        }
     }
     return HK_OK;
 }
@@ -1401,20 +1518,17 @@ extern "C" int hk_blob_finish_centers(hk_blob *b, int *counts_host,
                                       int *total) {
     if (!counts_host || !centers_host || !total)
         return hk::fail(HK_ERR_ARG, "hk_blob_finish_centers: null argument");
-    std::vector<std::vector<Center>> frames;
+    Contours frames;
     const int rc = collect(b, frames);
     if (rc != HK_OK) return rc;
-    int n = 0;
-    for (size_t f = 0; f < frames.size(); ++f) {
-        counts_host[f] = (int)frames[f].size();
-        for (const Center &c : frames[f]) {
-            if (n < cap) {
-                centers_host[3 * n] = c.x;
-                centers_host[3 * n + 1] = c.y;
-                centers_host[3 * n + 2] = c.radius;
-            }
-            ++n;
-        }
+    const int n = (int)frames.centers.size();
+    for (size_t f = 0; f < frames.frames(); ++f)
+        counts_host[f] = frames.off[f + 1] - frames.off[f];
+    for (int i = 0; i < n && i < cap; ++i) {
+        const Center &c = frames.centers[(size_t)i];
+        centers_host[3 * i] = c.x;
+        centers_host[3 * i + 1] = c.y;
+        centers_host[3 * i + 2] = c.radius;
     }
     *total = n;
     if (n > cap) {
@@ -1430,14 +1544,16 @@ extern "C" int hk_blob_finish(hk_blob *b, int *counts_host, float *kp_host,
                               int cap, int *total) {
     if (!counts_host || !kp_host || !total)
         return hk::fail(HK_ERR_ARG, "hk_blob_finish: null argument");
-    std::vector<std::vector<Center>> frames;
+    Contours frames;
     const int rc = collect(b, frames);
     if (rc != HK_OK) return rc;
     int n = 0;
-    std::vector<float> kp;
-    for (size_t f = 0; f < frames.size(); ++f) {
+    static thread_local std::vector<float> kp;
+    for (size_t f = 0; f < frames.frames(); ++f) {
         kp.clear();
-        group_keypoints(frames[f], b->n_thresholds, b->params, kp);
+        group_keypoints(frames.centers.data() + frames.off[f],
+                        (size_t)(frames.off[f + 1] - frames.off[f]),
+                        b->n_thresholds, b->params, kp);
         const int k = (int)(kp.size() / 3);
         counts_host[f] = k;
         for (int i = 0; i < k; ++i, ++n)

@@ -198,12 +198,14 @@ class SimpleBlobDetector:
         self._keep = None
 
     def _split(self, flat, total):
+        # one copy of the batch's rows; the per-frame arrays are views of it
+        rows = flat[:total].copy()
+        ends = np.cumsum(self._counts[:self._pending]).tolist()
+        assert (ends[-1] if ends else 0) == total
         out, k = [], 0
-        for t in range(self._pending):
-            n = int(self._counts[t])
-            out.append(flat[k:k + n].copy())
-            k += n
-        assert k == total
+        for e in ends:
+            out.append(rows[k:e])
+            k = e
         self._pending = 0
         self._keep = None
         return out
