@@ -288,6 +288,7 @@ def launch_times(timing):
 
 
 def run_clips(args, world, rank, local):
+    xdev = 'cuda' if args.backend == 'nccl' else 'cpu'  # exchange buffers
     spec = dict(synth.CLIPS[WORKLOAD])
     spec['seed'] += rank                    # one clip per GPU
     if args.frames:
@@ -368,16 +369,16 @@ def run_clips(args, world, rank, local):
     tags_left, tilt = int(result.alive.sum()), result.camera_tilt
     # collect every rank's arc table on rank 0 (RCCL), and the slowest time
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         n_arcs = torch.tensor([len(arc_params)], dtype=torch.int64,
-                              device='cuda')
+                              device=xdev)
         counts = [torch.zeros_like(n_arcs) for _ in range(world)]
         dist.all_gather(counts, n_arcs)
         cap = int(max(c.item() for c in counts))
-        mine = torch.zeros((cap, 5), dtype=torch.float64, device='cuda')
-        mine[:len(arc_params)] = torch.from_numpy(arc_params).cuda()
+        mine = torch.zeros((cap, 5), dtype=torch.float64, device=xdev)
+        mine[:len(arc_params)] = torch.from_numpy(arc_params).to(xdev)
         tables = [torch.zeros_like(mine) for _ in range(world)] \
             if rank == 0 else None
         dist.gather(mine, tables, dst=0)
@@ -487,6 +488,7 @@ def nearest_match_rate(kept, ref, tol=0.5):
 
 
 def run_segments(args, world, rank, local):
+    xdev = 'cuda' if args.backend == 'nccl' else 'cpu'  # exchange buffers
     from hawkeye_amd.frames import SyntheticSource
     spec = dict(synth.CLIPS[SEGMENT_WORKLOAD])
     if args.frames:
@@ -498,7 +500,7 @@ def run_segments(args, world, rank, local):
     resident = (end - first) * frame_bytes <= 0.72 * total_mem
     # all ranks take the same route, so that the line describes one thing
     if world > 1:
-        flag = torch.tensor([1 if resident else 0], device='cuda')
+        flag = torch.tensor([1 if resident else 0], device=xdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         resident = bool(flag.item())
     if resident:
@@ -551,7 +553,7 @@ def run_segments(args, world, rank, local):
     det.mog_timing = None
     det.mog_timing_every = 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -643,6 +645,12 @@ def main():
     ap.add_argument('--time-every', type=int, default=8,
                     help='bracket every n-th MOG launch of the timed region '
                          'with timing events (roofline.launch_ms)')
+    ap.add_argument('--backend', default='nccl',
+                    help="torch.distributed backend for N > 1 ('nccl' = RCCL; "
+                         "'gloo' only to rehearse the control flow)")
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='every rank uses GPU 0 (rehearsal on a one-GPU box; '
+                         'the numbers mean nothing)')
     ap.add_argument('--cpu-sample', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=None,
@@ -667,9 +675,15 @@ def main():
                      'torch.distributed.run --nproc-per-node {}'.format(
                          args.gpus, args.gpus))
         args.gpus = world
+    if args.share_gpu:      # rehearsal of the N > 1 control flow on one GPU
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl',
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend)
 
     run = run_clips if args.layout == 'clips' else run_segments
     out = run(args, world, rank, local)

@@ -230,10 +230,12 @@ static S3Prof g_s3prof;         // single-thread measurements only
 #define S3P_T0 const unsigned long long s3p_t0 = __rdtsc()
 #define S3P_ADD(k) do { g_s3prof.cyc[k] += __rdtsc() - s3p_t0; ++g_s3prof.cnt[k]; } while (0)
 #define S3P_CNT(k, n) (g_s3prof.cnt[k] += (n))
+#define S3P_BUILD (g_s3prof.cyc[6] += __rdtsc() - s3p_t0)
 #else
 #define S3P_T0 do {} while (0)
 #define S3P_ADD(k) do {} while (0)
 #define S3P_CNT(k, n) do {} while (0)
+#define S3P_BUILD do {} while (0)
 #endif
 
 // Full passes in progress that threads from outside may join
@@ -862,7 +864,9 @@ private:
         if (st != 2) {
             uint8_t expected = 0;
             if (nb_state_[i].compare_exchange_strong(expected, 1)) {
+                S3P_T0;
                 build_neighbors(i, s);
+                S3P_BUILD;
                 nb_state_[i].store(2, std::memory_order_release);
             } else {
                 while (nb_state_[i].load(std::memory_order_acquire) != 2)
@@ -1935,7 +1939,7 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
         if (stats) {
             static const char *nm[8] = {"frontier init", "distance scan + min",
                 "frontier add (growth)", "fit", "member check", "seed nb list",
-                "frontier tags scanned", "trials"};
+                "nb list builds (cyc) / frontier tags scanned (n)", "trials"};
             for (int k = 0; k < 8; ++k)
                 fprintf(stderr, "  s3prof %-24s %8.2f Mcyc  n=%llu\n", nm[k],
                         hk::g_s3prof.cyc[k] / 1e6, hk::g_s3prof.cnt[k]);
