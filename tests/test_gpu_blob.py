@@ -207,3 +207,95 @@ def test_rejects_non_binary_mask_and_bad_params():
     p.maxArea = 50000.0
     with pytest.raises(nat.NativeError, match='points'):
         SimpleBlobDetector(64, 48, params=p)
+
+
+def test_shapes_that_stress_the_candidate_pruning():
+    """The scan kernels drop border-start candidates that a look at the row
+    above shows not to be starts (prune_candidates).  Shapes made for that
+    rule: combs with teeth up (many outer candidates in one component) and
+    down (many hole candidates in the outer background), U shapes, rings
+    with a notch, nested rings, a ring whose hole starts under a run that is
+    only partly covered, blobs cut by every image edge, a checkerboard, and
+    one-pixel-wide diagonals.  With and without the colour filter, at a size
+    that goes through the tile hand-over as well."""
+    h, w = 128, 160
+    m = np.zeros((6, h, w), np.uint8)
+    # 0: combs
+    m[0, 20:24, 10:70] = 255
+    for x in range(10, 70, 4):
+        m[0, 12:20, x:x + 2] = 255          # teeth up
+    m[0, 60:64, 10:70] = 255
+    for x in range(10, 70, 6):
+        m[0, 64:72, x:x + 3] = 255          # teeth down
+    m[0, 90:100, 90:94] = 255               # U
+    m[0, 90:100, 100:104] = 255
+    m[0, 98:102, 90:104] = 255
+    # 1: rings, notched rings, nested rings
+    yy, xx = np.mgrid[0:h, 0:w]
+    for cx, cy, ro, ri in ((30, 30, 12, 6), (80, 30, 14, 9), (125, 35, 16, 4)):
+        d2 = (xx - cx) ** 2 + (yy - cy) ** 2
+        m[1][(d2 <= ro * ro) & (d2 >= ri * ri)] = 255
+    m[1, 16:24, 84:87] = 0                  # notch through the top of a ring
+    d2 = (xx - 60) ** 2 + (yy - 90) ** 2
+    m[1][(d2 <= 30 * 30) & (d2 >= 24 * 24)] = 255
+    m[1][(d2 <= 18 * 18) & (d2 >= 12 * 12)] = 255
+    m[1][d2 <= 5 * 5] = 255
+    # 2: holes whose first row lies under a partly covered run
+    m[2, 20:40, 20:60] = 255
+    m[2, 25:35, 30:50] = 0
+    m[2, 24, 44:50] = 0                     # the hole's top is a step
+    m[2, 60:80, 20:60] = 255
+    m[2, 65:75, 30:50] = 0
+    m[2, 60:65, 40] = 0                     # a slit from the hole to outside
+    m[2, 90:110, 100:140] = 255
+    m[2, 95:105, 110:130] = 0
+    m[2, 100, 105:112] = 0                  # a side pocket, lower than the top
+    # 3: blobs cut by the edges
+    for cx, cy in ((0, 0), (w - 1, 0), (0, h - 1), (w - 1, h - 1),
+                   (w // 2, 0), (w - 1, h // 2), (0, h // 2), (w // 2, h - 1)):
+        m[3][(xx - cx) ** 2 + (yy - cy) ** 2 <= 81] = 255
+    m[3, 40:50, w - 6:w] = 255
+    m[3, 43:47, w - 3:w] = 0                # a bay open to the right edge
+    # 4: checkerboard and diagonals
+    m[4][((xx // 3 + yy // 3) % 2 == 0) & (xx < 60) & (yy < 60)] = 255
+    for k in range(40):
+        m[4, 70 + k, 20 + k] = 255
+        m[4, 70 + k, 100 - k] = 255
+        m[4, 70 + k, 101 - k] = 255
+    # 5: everything at once, shifted by 31/33 pixels (word boundaries)
+    m[5] = np.roll(np.roll(m[0] | m[1], 31, axis=1), 3, axis=0) | \
+        np.roll(m[2], 33, axis=1)
+    for by_color in (True, False):
+        n_c, _ = check_against_oracle(m, params_height=480, by_color=by_color)
+        assert n_c > 10
+    # the same through the 1-bit tile hand-over
+    import ctypes
+    from hawkeye_amd.detect import SimpleBlobDetector, hawkeye_blob_params
+    from oracle import detect_ref as D
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_blob', os.path.join(os.path.dirname(__file__), 'fuzz_blob.py'))
+    fuzz_blob = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz_blob)
+    pack_tiles = fuzz_blob.pack_tiles
+    for by_color in (True, False):
+        p = D.hawkeye_params(480)
+        p.filterByColor = 1 if by_color else 0
+        want = [D.find_blobs(f, p) for f in m]
+        params = hawkeye_blob_params(480)
+        params.filterByColor = 1 if by_color else 0
+        det = SimpleBlobDetector(w, h, params=params, max_frames=len(m))
+        packed = torch.from_numpy(pack_tiles(m).view(np.int32)).cuda()
+        torch.cuda.synchronize()
+        hip = ctypes.CDLL('libamdhip64.so')
+        assert hip.hipMemcpy(ctypes.c_void_p(det.tiles_buffer()),
+                             ctypes.c_void_p(packed.data_ptr()),
+                             ctypes.c_size_t(packed.numel() * 4), 3) == 0
+        det.enqueue_tiles(len(m))
+        got = det.finish_centers()
+        for f in range(len(m)):
+            assert got[f].shape == want[f].shape, (by_color, f)
+            assert np.array_equal(got[f].view(np.uint64),
+                                  want[f].view(np.uint64)), (by_color, f)
+        det.close()
