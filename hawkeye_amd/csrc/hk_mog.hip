@@ -480,6 +480,18 @@ __device__ __forceinline__ void write_lane_x4(unsigned &a0, unsigned &a1,
 // MASKS: byte masks are written (hk_mog_apply_batch); TILES: the 1-bit tile
 // words are (hk_mog_apply_batch_tiles, TILED geometry only).
 // ---------------------------------------------------------------------------
+// tools/probe build only (-DHK_MOG_PATH_STATS): how many wave-frames take
+// which update path (tools/probe/mog_paths.py)
+#ifdef HK_MOG_PATH_STATS
+__device__ unsigned long long hk_mog_path_stats_dev[8];
+#define HK_PATH_STAT(i)                                                      \
+    do {                                                                      \
+        if (threadIdx.x == 0) atomicAdd(&hk_mog_path_stats_dev[i], 1ull);     \
+    } while (0)
+#else
+#define HK_PATH_STAT(i) do {} while (0)
+#endif
+
 template <int WAVES, int DEPTH, bool TILED, bool MASKS, bool TILES>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
@@ -661,6 +673,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                     if (near == all_lanes) {
                         asm volatile("; unit step");
                         unit_update(px, vsum, pr, cur_alpha[j]);
+                        HK_PATH_STAT(0);
                         unit_frames = j + 1;
                         if (MASKS)      // all background
                             *reinterpret_cast<unsigned short *>(
@@ -705,6 +718,7 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                 if (hits == all_lanes) {
                     asm volatile("; every lane on its first component");
                     cum = weighted_update(px, lazy, vsum, nc, pr, alpha);
+                    HK_PATH_STAT(nc < 3 ? nc : 3);
                 } else {
                     if (hit) {
                         cum = weighted_update(px, lazy, vsum, nc, pr, alpha);
@@ -726,6 +740,8 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
                     }
                     ++slow_steps;
                     recount = true;
+                    HK_PATH_STAT(__builtin_amdgcn_ballot_w64(hit) ==
+                                         all_lanes ? 4 : 5);
                 }
                 // components only ever get more, and only in the general
                 // step; a wave of single components is looked at after every
@@ -1398,3 +1414,15 @@ extern "C" int hk_mog_selfcheck_math(int device, long long *mismatches_out) {
     return HK_OK;
 }
 
+
+#ifdef HK_MOG_PATH_STATS
+extern "C" int hk_mog_path_stats(unsigned long long *out) {
+    unsigned long long zero[8] = {0};
+    HK_HIP(hipDeviceSynchronize());
+    HK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hk_mog_path_stats_dev),
+                               sizeof(zero)));
+    HK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hk_mog_path_stats_dev), zero,
+                             sizeof(zero)));
+    return HK_OK;
+}
+#endif
