@@ -94,6 +94,13 @@ struct BlobRec {
     double d2lo, d2hi;      // middle order statistics of squared distances
 };
 
+// What the host reads back per surviving contour (written by blob_radius_k).
+struct HostRec {
+    uint32_t key;           // as BlobRec::key
+    int32_t frame;
+    double cx, cy, radius;  // radius = mean of the two middle distances
+};
+
 struct DevParams {
     int filterByColor, blobColor;
     double minArea, maxArea, minCirc, maxCirc;
@@ -821,8 +828,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
 __global__ __launch_bounds__(64) void blob_radius_k(
     const unsigned *__restrict__ ctr, unsigned cap_blob,
     BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts,
-    const ushort2 *__restrict__ tmp_pts) {
+    const ushort2 *__restrict__ tmp_pts, HostRec *__restrict__ hrecs) {
     __shared__ double d2[MAXPTS];
+    __shared__ double mid[2];
     unsigned n = ctr[CTR_NBLOB];
     if (n > cap_blob) n = cap_blob;
     const int lane = threadIdx.x;
@@ -847,8 +855,22 @@ __global__ __launch_bounds__(64) void blob_radius_k(
                 const double u = d2[j];
                 rank += (u < v) || (u == v && j < i);
             }
-            if (rank == lo) recs[slot].d2lo = v;
-            if (rank == hi) recs[slot].d2hi = v;
+            if (rank == lo) mid[0] = v;
+            if (rank == hi) mid[1] = v;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            // sort + middle of OpenCV's dists vector: (dists[(n-1)/2] +
+            // dists[n/2]) / 2 with dists = the roots (IEEE sqrt, monotonic)
+            recs[slot].d2lo = mid[0];
+            recs[slot].d2hi = mid[1];
+            HostRec h;
+            h.key = recs[slot].key;
+            h.frame = recs[slot].frame;
+            h.cx = cx;
+            h.cy = cy;
+            h.radius = (sqrt(mid[0]) + sqrt(mid[1])) / 2.;
+            hrecs[slot] = h;
         }
         __syncthreads();
     }
@@ -929,10 +951,32 @@ void group_keypoints(const Center *cur, size_t n, int n_thresholds,
     // (a detection thread calls this for every frame: the scratch vectors
     // live across calls)
     static thread_local std::vector<char> linked;
+    static thread_local std::vector<int> by_y;
     linked.assign(n, 0);
     bool any = false;
-    for (size_t i = 0; i < n; ++i)
-        for (size_t j = i + 1; j < n; ++j) {
+    // Two centres can only be matched if they are closer than the largest of
+    // minDistBetweenBlobs and their radii: with the centres in order of y
+    // (a few dozen per frame: insertion sort) each one is tested against
+    // those within that bound below it instead of against all the others.
+    // Which pairs are tested does not matter to the outcome, only whether a
+    // centre has any partner.
+    double bound = min_dist;
+    by_y.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (cur[i].radius > bound) bound = cur[i].radius;
+        int k = (int)i;
+        while (k > 0 && cur[(size_t)by_y[(size_t)k - 1]].y > cur[i].y) {
+            by_y[(size_t)k] = by_y[(size_t)k - 1];
+            --k;
+        }
+        by_y[(size_t)k] = (int)i;
+    }
+    const double reach = bound * (1 + 1e-9);
+    for (size_t a = 0; a < n; ++a)
+        for (size_t b = a + 1; b < n; ++b) {
+            const size_t i = (size_t)by_y[a], j = (size_t)by_y[b];
+            // (centres are quotients of finite sums with m00 != 0: finite)
+            if (cur[j].y - cur[i].y > reach) break;
             const double ddx = cur[i].x - cur[j].x, ddy = cur[i].y - cur[j].y;
             const double q = ddx * ddx + ddy * ddy;
             // "dist >= min_dist, radius i and radius j" with dist = sqrt(q):
@@ -966,6 +1010,26 @@ void group_keypoints(const Center *cur, size_t n, int n_thresholds,
         first_pass = sub.size();
         replay_groups(sub, n_thresholds, p, groups);
     }
+    // An isolated centre ends as a group of n_thresholds copies of itself:
+    // the same sequential sums as emit_group() makes, for all centres of the
+    // frame side by side (the additions of different centres do not depend
+    // on each other: the compiler vectorises the inner loops)
+    static thread_local std::vector<double> sums;
+    sums.resize(4 * n);
+    double *const sx = sums.data(), *const sy = sx + n, *const cx = sy + n,
+                 *const cy = cx + n;
+    double normalizer = 0;
+    for (size_t i = 0; i < n; ++i) {
+        cx[i] = 1.0 * cur[i].x;
+        cy[i] = 1.0 * cur[i].y;
+        sx[i] = sy[i] = 0;
+    }
+    for (int k = 0; k < n_thresholds; ++k) {
+        for (size_t i = 0; i < n; ++i) sx[i] += cx[i];
+        for (size_t i = 0; i < n; ++i) sy[i] += cy[i];
+        normalizer += 1.0;
+    }
+    const double inv = 1. / normalizer;
     size_t next_sub = 0;
     for (size_t i = 0; i < n; ++i) {
         if (linked[i]) {
@@ -973,18 +1037,8 @@ void group_keypoints(const Center *cur, size_t n, int n_thresholds,
             if ((int)g.size() >= p.minRepeatability)
                 emit_group(g.data(), g.size(), out);
         } else if (n_thresholds >= p.minRepeatability) {
-            // n_thresholds copies of the centre: the same sequential sums
-            double sx = 0, sy = 0, normalizer = 0;
-            for (int k = 0; k < n_thresholds; ++k) {
-                sx += 1.0 * cur[i].x;
-                sy += 1.0 * cur[i].y;
-                normalizer += 1.0;
-            }
-            const double inv = 1. / normalizer;
-            sx *= inv;
-            sy *= inv;
-            out.push_back((float)sx);
-            out.push_back((float)sy);
+            out.push_back((float)(sx[i] * inv));
+            out.push_back((float)(sy[i] * inv));
             out.push_back((float)(cur[i].radius) * 2.0f);
         }
     }
@@ -1027,7 +1081,8 @@ struct hk_blob {
     uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
     int words_per_row = 0;              // (W + 31) / 32 + 2, rounded up to 4
     unsigned *h_ctr = nullptr;          // pinned
-    BlobRec *h_recs = nullptr;          // pinned, cap_blob entries
+    HostRec *hrecs = nullptr;           // device, cap_blob entries
+    HostRec *h_recs = nullptr;          // pinned, cap_blob entries
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;
     int pending_frames = 0;             // batch between enqueue and finish
@@ -1070,6 +1125,7 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->cands);
     (void)hipFree(b->ctr);
     (void)hipFree(b->recs);
+    (void)hipFree(b->hrecs);
     (void)hipFree(b->pts);
     (void)hipFree(b->tmp_pts);
     (void)hipFree(b->active);
@@ -1167,6 +1223,8 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->recs, sizeof(BlobRec) * b->cap_blob);
     if (e == hipSuccess)
+        e = hipMalloc((void **)&b->hrecs, sizeof(HostRec) * b->cap_blob);
+    if (e == hipSuccess)
         e = hipMalloc((void **)&b->pts,
                       sizeof(ushort2) * MAXPTS * (size_t)b->cap_blob);
     // a first-pass point list per candidate traced: 256 per frame is a few
@@ -1185,7 +1243,7 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&b->h_ctr, sizeof(unsigned) * CTR_WORDS);
     if (e == hipSuccess)
-        e = hipHostMalloc((void **)&b->h_recs, sizeof(BlobRec) * b->cap_blob);
+        e = hipHostMalloc((void **)&b->h_recs, sizeof(HostRec) * b->cap_blob);
     if (e == hipSuccess)
         e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming |
                                                   hipEventBlockingSync);
@@ -1263,11 +1321,11 @@ static int launch_batch(hk_blob *b, int nframes) {
     }();
     hipLaunchKernelGGL(blob_radius_k, dim3(radius_grid), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts,
-                       (const ushort2 *)b->tmp_pts);
+                       (const ushort2 *)b->tmp_pts, b->hrecs);
     HK_LAUNCH_CHECK("blob_radius_k");
     HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
                           hipMemcpyDeviceToHost, s));
-    HK_HIP(hipMemcpyAsync(b->h_recs, b->recs, sizeof(BlobRec) * b->eager,
+    HK_HIP(hipMemcpyAsync(b->h_recs, b->hrecs, sizeof(HostRec) * b->eager,
                           hipMemcpyDeviceToHost, s));
     HK_HIP(hipEventRecord(b->done, s));
     return HK_OK;
@@ -1373,16 +1431,19 @@ static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
         unsigned cap = b->cap_blob;
         while (cap < b->h_ctr[CTR_NBLOB]) cap *= 4;
         (void)hipFree(b->recs);
+        (void)hipFree(b->hrecs);
         (void)hipFree(b->pts);
         (void)hipHostFree(b->h_recs);
         b->recs = nullptr;
+        b->hrecs = nullptr;
         b->pts = nullptr;
         b->h_recs = nullptr;
         b->cap_blob = cap;
         HK_HIP(hipMalloc((void **)&b->recs, sizeof(BlobRec) * cap));
+        HK_HIP(hipMalloc((void **)&b->hrecs, sizeof(HostRec) * cap));
         HK_HIP(hipMalloc((void **)&b->pts,
                          sizeof(ushort2) * MAXPTS * (size_t)cap));
-        HK_HIP(hipHostMalloc((void **)&b->h_recs, sizeof(BlobRec) * cap));
+        HK_HIP(hipHostMalloc((void **)&b->h_recs, sizeof(HostRec) * cap));
     }
     const int rc = launch_batch(b, nframes);
     if (rc != HK_OK) return rc;
@@ -1467,47 +1528,49 @@ static int collect(hk_blob *b, Contours &frames) {
     }
     const unsigned nblob = b->h_ctr[CTR_NBLOB];
     if (nblob > b->eager) {
-        HK_HIP(hipMemcpyAsync(b->h_recs + b->eager, b->recs + b->eager,
-                              sizeof(BlobRec) * (nblob - b->eager),
+        HK_HIP(hipMemcpyAsync(b->h_recs + b->eager, b->hrecs + b->eager,
+                              sizeof(HostRec) * (nblob - b->eager),
                               hipMemcpyDeviceToHost, b->stream));
         HK_HIP(hipStreamSynchronize(b->stream));
     }
-    // by frame (counting sort), within a frame last discovered first
-    // (descending key; a few dozen per frame)
+    // The records the radius kernel left for the host (32 bytes each, pinned
+    // memory): by frame (counting sort), within a frame last discovered
+    // first (descending key; a few dozen per frame).
+    const HostRec *const lite = b->h_recs;
+    static thread_local std::vector<unsigned> slot, fill;
     std::vector<int> &off = frames.off;
     off.assign((size_t)nframes + 1, 0);
     for (unsigned i = 0; i < nblob; ++i) {
-        const int f = b->h_recs[i].frame;
+        const int f = lite[i].frame;
         if (f < 0 || f >= nframes)
             return hk::fail(HK_ERR_INTERNAL, "hk_blob: bad frame index");
         ++off[(size_t)f + 1];
     }
     for (int f = 0; f < nframes; ++f) off[(size_t)f + 1] += off[(size_t)f];
-    static thread_local std::vector<unsigned> slot, fill;
     slot.resize(nblob);
     fill.assign(off.begin(), off.end() - 1);
     for (unsigned i = 0; i < nblob; ++i)
-        slot[fill[(size_t)b->h_recs[i].frame]++] = i;
+        slot[fill[(size_t)lite[i].frame]++] = i;
     frames.centers.resize(nblob);
     for (int f = 0; f < nframes; ++f) {
         unsigned *lo = slot.data() + off[(size_t)f];
         unsigned *hi = slot.data() + off[(size_t)f + 1];
         for (unsigned *p = lo + 1; p < hi; ++p) {       // insertion sort
             const unsigned v = *p;
-            const uint32_t key = b->h_recs[v].key;
+            const uint32_t key = lite[v].key;
             unsigned *q = p;
-            while (q > lo && b->h_recs[q[-1]].key < key) {
+            while (q > lo && lite[q[-1]].key < key) {
                 *q = q[-1];
                 --q;
             }
             *q = v;
         }
         for (unsigned *p = lo; p < hi; ++p) {
-            const BlobRec &r = b->h_recs[*p];
+            const HostRec &r = lite[*p];
             Center &c = frames.centers[(size_t)(p - slot.data())];
             c.x = r.cx;
             c.y = r.cy;
-            c.radius = (std::sqrt(r.d2lo) + std::sqrt(r.d2hi)) / 2.;
+            c.radius = r.radius;
         }
     }
     return HK_OK;
