@@ -72,16 +72,30 @@ class ClipResult:
                  'stage_seconds')
 
 
+class FrameEvents(list):
+    """The per-frame keypoint arrays of a clip (a plain list), with the same
+    data as two arrays: `counts` int [frames] and `rows` float32
+    [keypoints][3], all frames end to end."""
+    counts = None
+    rows = None
+
+
 def events_to_soa(per_frame, frame_width, frame_height, scan_width,
                   scan_height):
     """Keypoints -> the SoA arrays of notes['meas']: the float64 expressions
     of reference tracker.py:335-342, 413-417 (the blob *diameter* goes into
     Balltag.radius, as the reference does)."""
-    counts = np.fromiter((len(k) for k in per_frame), np.int64,
-                         len(per_frame))
+    if getattr(per_frame, 'rows', None) is not None:
+        # (a few array operations instead of 1800 small ones under the
+        # interpreter lock, which the detection thread needs every chunk)
+        counts = np.asarray(per_frame.counts, np.int64)
+        kp = per_frame.rows.astype(np.float64)
+    else:
+        counts = np.fromiter((len(k) for k in per_frame), np.int64,
+                             len(per_frame))
+        kp = (np.concatenate(per_frame) if counts.sum() else
+              np.zeros((0, 3), np.float32)).astype(np.float64)
     frame = np.repeat(np.arange(len(per_frame), dtype=np.int32), counts)
-    kp = (np.concatenate(per_frame) if counts.sum() else
-          np.zeros((0, 3), np.float32)).astype(np.float64)
     scale = frame_height / scan_height
     crop_w = frame_height * (scan_width / scan_height)
     pad_left = (frame_width - crop_w) / 2
@@ -128,7 +142,8 @@ class ClipScanner:
         """frames: uint8 [T][H][W][3] BGR on the device, or a frame source
         (hawkeye_amd.frames) with read().  Returns the per-frame keypoints."""
         det = self._det
-        out = []
+        out = FrameEvents()
+        det.batches = []
         # the caller may have produced the frames on its own stream a moment
         # ago (rendered, decoded, copied): order the detection stream after it
         self._detect_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -137,9 +152,20 @@ class ClipScanner:
             chunks = (self._from_source(frames) if hasattr(frames, 'read')
                       else (frames[s:s + self.chunk]
                             for s in range(0, frames.shape[0], self.chunk)))
-            for chunk in chunks:
-                out.extend(det.submit(chunk))
-            out.extend(det.flush())
+            try:
+                for chunk in chunks:
+                    out.extend(det.submit(chunk))
+                out.extend(det.flush())
+                batches = det.batches
+            finally:
+                det.batches = None
+        if batches:
+            out.counts = np.concatenate([c for c, _ in batches])
+            out.rows = np.concatenate([r for _, r in batches])
+        else:
+            out.counts = np.zeros(0, np.int32)
+            out.rows = np.zeros((0, 3), np.float32)
+        assert len(out.counts) == len(out)
         return out
 
     def _from_source(self, src):

@@ -146,6 +146,7 @@ class SimpleBlobDetector:
                                          nat.C.byref(h)))
         self._h = h
         self._cap = self.max_frames * 128
+        self.last_batch = None
         self._counts = np.empty(self.max_frames, np.int32)
         self._kp = np.empty((self._cap, 3), np.float32)
         self._centers = np.empty((self._cap, 3), np.float64)
@@ -200,7 +201,8 @@ class SimpleBlobDetector:
     def _split(self, flat, total):
         # one copy of the batch's rows; the per-frame arrays are views of it
         rows = flat[:total].copy()
-        ends = np.cumsum(self._counts[:self._pending]).tolist()
+        counts = self._counts[:self._pending].copy()
+        ends = np.cumsum(counts).tolist()
         assert (ends[-1] if ends else 0) == total
         out, k = [], 0
         for e in ends:
@@ -208,6 +210,9 @@ class SimpleBlobDetector:
             k = e
         self._pending = 0
         self._keep = None
+        # the same batch as two arrays, for callers that want all frames at
+        # once (EventDetector.batches)
+        self.last_batch = (counts, rows)
         return out
 
     def _finish_into(self, fn, name, dtype):
@@ -292,6 +297,9 @@ class EventDetector:
         # samples launches instead of bracketing all of them
         self.mog_timing = None
         self.mog_timing_every = 1
+        # set to a list to also get every collected chunk as (counts int32
+        # [frames], rows float32 [keypoints][3]), in order
+        self.batches = None
         self._side = torch.cuda.Stream(device=self.device)
         self._mog_done = [torch.cuda.Event() for _ in range(self.DEPTH)]
 
@@ -341,7 +349,10 @@ class EventDetector:
             return []
         p = self._collected % self.DEPTH
         self._collected += 1
-        return self.blob[p].finish()
+        out = self.blob[p].finish()
+        if self.batches is not None:
+            self.batches.append(self.blob[p].last_batch)
+        return out
 
     def flush(self):
         out = []
