@@ -173,7 +173,7 @@ def main():
     ap.add_argument('--step4', action='store_true')
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0 = time.time()
+    t0 = said = time.time()
     cases = 0
     tally = {}
     while time.time() - t0 < args.seconds:
@@ -181,6 +181,9 @@ def main():
         spec, meas = random_case(rng)
         err = compare(spec, meas, args.step4)
         cases += 1
+        if time.time() - said > 30:     # a silent GPU run is taken to be hung
+            print('...', cases, 'cases', flush=True)
+            said = time.time()
         if err:
             who, distinct = arbitrate(spec, meas)
             print('MISMATCH', err, spec, 'case', cases, 'rng', state,

@@ -72,7 +72,7 @@ def main():
     ap.add_argument('--seed', type=int, default=1)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0 = time.time()
+    t0 = said = time.time()
     cases = contours = tiled = 0
     while time.time() - t0 < args.seconds:
         w = int(rng.choice([rng.randint(33, 400), 64, 96, 320, 640, 641]))
@@ -113,6 +113,9 @@ def main():
         contours += sum(len(x) for x in want)
         det.close()
         cases += 1
+        if time.time() - said > 30:     # a silent GPU run is taken to be hung
+            print('...', cases, 'cases', flush=True)
+            said = time.time()
     print('fuzz_blob: {} cases ({} also through the tile hand-over), {} '
           'contours that passed the filters, no difference'.format(
               cases, tiled, contours))

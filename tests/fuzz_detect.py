@@ -78,13 +78,16 @@ def main():
     ap.add_argument('--max-pixels', type=int, default=300000)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0 = time.time()
+    t0 = said = time.time()
     cases = events = 0
     while time.time() - t0 < args.seconds:
         spec = random_spec(rng, args.max_pixels)
         chunk = int(rng.choice([1, 2, 7, 32, 128]))
         err, n = run_case(spec, chunk)
         cases += 1
+        if time.time() - said > 30:     # a silent GPU run is taken to be hung
+            print('...', cases, 'cases', flush=True)
+            said = time.time()
         events += n
         if err:
             print('MISMATCH', err, 'chunk', chunk, spec, flush=True)
