@@ -828,9 +828,16 @@ __global__ __launch_bounds__(TRACE_THREADS) void blob_trace_k(
 __global__ __launch_bounds__(64) void blob_radius_k(
     const unsigned *__restrict__ ctr, unsigned cap_blob,
     BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts,
-    const ushort2 *__restrict__ tmp_pts, HostRec *__restrict__ hrecs) {
+    const ushort2 *__restrict__ tmp_pts, HostRec *__restrict__ hrecs,
+    unsigned *__restrict__ h_ctr) {
     __shared__ double d2[MAXPTS];
     __shared__ double mid[2];
+    // hrecs and h_ctr are pinned host memory: what the host reads goes there
+    // straight from this kernel (no copy kernels behind it, which would queue
+    // for a slot beside the next chunk's MOG launch: 150 us per chunk).  The
+    // counters are final before this kernel starts.
+    if (blockIdx.x == 0 && threadIdx.x < CTR_WORDS)
+        h_ctr[threadIdx.x] = ctr[threadIdx.x];
     unsigned n = ctr[CTR_NBLOB];
     if (n > cap_blob) n = cap_blob;
     const int lane = threadIdx.x;
@@ -1067,7 +1074,7 @@ struct hk_blob {
     hk_blob_params params;
     DevParams dev;
     int n_thresholds = 0;
-    unsigned cap_blob = 0, eager = 0;
+    unsigned cap_blob = 0;
     int band_rows = 0, nbands = 0;      // K3 works on bands of rows,
     int ncols = 0;                      // in blocks of COL_WORDS words
     size_t trace_lds = 0;               // bytes of LDS a K3 workgroup needs
@@ -1081,8 +1088,9 @@ struct hk_blob {
     uint32_t *bits = nullptr;           // [max_frames][H + 2][words_per_row]
     int words_per_row = 0;              // (W + 31) / 32 + 2, rounded up to 4
     unsigned *h_ctr = nullptr;          // pinned
-    HostRec *hrecs = nullptr;           // device, cap_blob entries
-    HostRec *h_recs = nullptr;          // pinned, cap_blob entries
+    HostRec *h_recs = nullptr;          // pinned, cap_blob entries; the
+    HostRec *hrecs = nullptr;           // same memory as the device sees it,
+    unsigned *h_ctr_dev = nullptr;      // and h_ctr likewise
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;
     int pending_frames = 0;             // batch between enqueue and finish
@@ -1125,7 +1133,6 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     (void)hipFree(b->cands);
     (void)hipFree(b->ctr);
     (void)hipFree(b->recs);
-    (void)hipFree(b->hrecs);
     (void)hipFree(b->pts);
     (void)hipFree(b->tmp_pts);
     (void)hipFree(b->active);
@@ -1209,7 +1216,6 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     }
     const size_t nbuckets = (size_t)max_frames * b->nbands * b->ncols;
     b->cap_blob = (unsigned)max_frames * 128u;
-    b->eager = std::min(b->cap_blob, (unsigned)max_frames * 48u);
 
     hipError_t e = hipMalloc((void **)&b->cands,
                              sizeof(Cand) * b->band_cap * nbuckets);
@@ -1222,8 +1228,6 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
                                 TRACE_LDS_BYTES);
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->recs, sizeof(BlobRec) * b->cap_blob);
-    if (e == hipSuccess)
-        e = hipMalloc((void **)&b->hrecs, sizeof(HostRec) * b->cap_blob);
     if (e == hipSuccess)
         e = hipMalloc((void **)&b->pts,
                       sizeof(ushort2) * MAXPTS * (size_t)b->cap_blob);
@@ -1243,7 +1247,11 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&b->h_ctr, sizeof(unsigned) * CTR_WORDS);
     if (e == hipSuccess)
+        e = hipHostGetDevicePointer((void **)&b->h_ctr_dev, b->h_ctr, 0);
+    if (e == hipSuccess)
         e = hipHostMalloc((void **)&b->h_recs, sizeof(HostRec) * b->cap_blob);
+    if (e == hipSuccess)
+        e = hipHostGetDevicePointer((void **)&b->hrecs, b->h_recs, 0);
     if (e == hipSuccess)
         e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming |
                                                   hipEventBlockingSync);
@@ -1321,12 +1329,8 @@ static int launch_batch(hk_blob *b, int nframes) {
     }();
     hipLaunchKernelGGL(blob_radius_k, dim3(radius_grid), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts,
-                       (const ushort2 *)b->tmp_pts, b->hrecs);
+                       (const ushort2 *)b->tmp_pts, b->hrecs, b->h_ctr_dev);
     HK_LAUNCH_CHECK("blob_radius_k");
-    HK_HIP(hipMemcpyAsync(b->h_ctr, b->ctr, sizeof(unsigned) * CTR_WORDS,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipMemcpyAsync(b->h_recs, b->hrecs, sizeof(HostRec) * b->eager,
-                          hipMemcpyDeviceToHost, s));
     HK_HIP(hipEventRecord(b->done, s));
     return HK_OK;
 }
@@ -1431,7 +1435,6 @@ static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
         unsigned cap = b->cap_blob;
         while (cap < b->h_ctr[CTR_NBLOB]) cap *= 4;
         (void)hipFree(b->recs);
-        (void)hipFree(b->hrecs);
         (void)hipFree(b->pts);
         (void)hipHostFree(b->h_recs);
         b->recs = nullptr;
@@ -1440,10 +1443,10 @@ static int grow_and_rerun(hk_blob *b, int nframes, bool band_full) {
         b->h_recs = nullptr;
         b->cap_blob = cap;
         HK_HIP(hipMalloc((void **)&b->recs, sizeof(BlobRec) * cap));
-        HK_HIP(hipMalloc((void **)&b->hrecs, sizeof(HostRec) * cap));
         HK_HIP(hipMalloc((void **)&b->pts,
                          sizeof(ushort2) * MAXPTS * (size_t)cap));
         HK_HIP(hipHostMalloc((void **)&b->h_recs, sizeof(HostRec) * cap));
+        HK_HIP(hipHostGetDevicePointer((void **)&b->hrecs, b->h_recs, 0));
     }
     const int rc = launch_batch(b, nframes);
     if (rc != HK_OK) return rc;
@@ -1527,12 +1530,6 @@ static int collect(hk_blob *b, Contours &frames) {
         if (rc != HK_OK) return rc;
     }
     const unsigned nblob = b->h_ctr[CTR_NBLOB];
-    if (nblob > b->eager) {
-        HK_HIP(hipMemcpyAsync(b->h_recs + b->eager, b->hrecs + b->eager,
-                              sizeof(HostRec) * (nblob - b->eager),
-                              hipMemcpyDeviceToHost, b->stream));
-        HK_HIP(hipStreamSynchronize(b->stream));
-    }
     // The records the radius kernel left for the host (32 bytes each, pinned
     // memory): by frame (counting sort), within a frame last discovered
     // first (descending key; a few dozen per frame).
