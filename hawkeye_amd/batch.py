@@ -20,6 +20,7 @@ detects the clips ahead on its own HIP stream, and a pool of builder threads
 step-3 builds in progress.  Results are the same as scanning the clips one by
 one, and come in the same order.
 """
+import collections
 import os
 import queue
 import threading
@@ -168,6 +169,84 @@ class ClipScanner:
         assert len(out.counts) == len(out)
         return out
 
+    def detect_many(self, clips, emit):
+        """Step 2 of one clip after the other without draining the chunk
+        pipeline in between: the first MOG launches of a clip are queued
+        while the blob kernels and the host-side finish of the previous
+        clip's last chunks are still to come (a drained pipeline costs about
+        1 ms of GPU idle time per clip of the 1080p benchmark, 11 %).  Calls
+        emit(per_frame, seconds) once per clip, in order; `seconds` is the
+        time the clip added to the stream of results.  Same events as
+        detect() clip by clip.  The next clip is taken from `clips` before
+        the previous one's last chunks are collected: an iterator that takes
+        long to produce a clip delays those results by that time."""
+        det = self._det
+        det.collected = []
+        open_clips = collections.deque()
+        last_done = [time.perf_counter()]
+
+        def drain():
+            for state, out, batch in det.collected:
+                state['out'].extend(out)
+                state['batches'].append(batch)
+                state['collected'] += 1
+            del det.collected[:]
+            while open_clips and open_clips[0]['closed'] and \
+                    open_clips[0]['collected'] == open_clips[0]['submitted']:
+                state = open_clips.popleft()
+                out = state['out']
+                if state['batches']:
+                    out.counts = np.concatenate(
+                        [c for c, _ in state['batches']])
+                    out.rows = np.concatenate([r for _, r in state['batches']])
+                else:
+                    out.counts = np.zeros(0, np.int32)
+                    out.rows = np.zeros((0, 3), np.float32)
+                assert len(out.counts) == len(out)
+                now = time.perf_counter()
+                since = max(last_done[0], state['t0'])
+                last_done[0] = now
+                emit(out, now - since)
+
+        try:
+            for frames in clips:
+                state = {'out': FrameEvents(), 'batches': [], 'submitted': 0,
+                         'collected': 0, 'closed': False,
+                         't0': time.perf_counter()}
+                open_clips.append(state)
+                self._detect_stream.wait_stream(
+                    torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._detect_stream):
+                    det.mog.reset()
+                    chunks = (self._from_source(frames)
+                              if hasattr(frames, 'read') else
+                              (frames[s:s + self.chunk] for s in
+                               range(0, frames.shape[0], self.chunk)))
+                    for chunk in chunks:
+                        det.submit(chunk, tag=state)
+                        state['submitted'] += 1
+                        if det.collected:
+                            drain()
+                state['closed'] = True
+                drain()
+            with torch.cuda.stream(self._detect_stream):
+                det.flush()
+            drain()
+        except BaseException:
+            # leave the detector empty, and let the clips that were complete
+            # but for their last chunks reach the caller before the error
+            try:
+                if open_clips:
+                    open_clips.pop()            # the clip that failed
+                with torch.cuda.stream(self._detect_stream):
+                    det.flush()
+                drain()
+            except Exception:       # noqa: BLE001 - the first error counts
+                pass
+            raise
+        finally:
+            det.collected = None
+
     def _from_source(self, src):
         while True:
             chunk = src.read(self.chunk)
@@ -251,13 +330,18 @@ class ClipScanner:
             cores = host_core_share()
         return max(1, cores - 1), 1
 
-    def scan_many(self, clips, host_threads=None, builders=None, count=None):
+    def scan_many(self, clips, host_threads=None, builders=None, count=None,
+                  lookahead=None):
         """Generator over the results of `clips` (an iterable of frame
         tensors / sources of this scanner's size), in order.  Detection of
         later clips (GPU, one worker thread) runs beside steps 3-4 of earlier
         ones (`builders` threads, a clip each; step 3 on `host_threads` worker
         threads per clip).  `count` = number of clips if `clips` cannot tell
-        (a generator); unused today, kept for callers that pass it."""
+        (a generator); unused today, kept for callers that pass it.
+        `lookahead` (default on): detection starts on the next clip before
+        the last chunks of the previous one are collected (detect_many)."""
+        if lookahead is None:
+            lookahead = os.environ.get('HK_DETECT_LOOKAHEAD', '1') != '0'
         if count is None and hasattr(clips, '__len__'):
             count = len(clips)
         if builders is None and host_threads is None:
@@ -291,16 +375,27 @@ class ClipScanner:
             seq = 0
             try:
                 torch.cuda.set_device(self.device)
-                for frames in clips:
-                    if stop.is_set():
-                        return
-                    t0 = time.perf_counter()
-                    per_frame = self.detect(frames)
+
+                def until_stopped():
+                    for frames in clips:
+                        if stop.is_set():
+                            return
+                        yield frames
+
+                def emit(per_frame, seconds):
+                    nonlocal seq
                     res = ClipResult()
-                    self._stage(res, 'detect', time.perf_counter() - t0)
-                    if not put(detected, (seq, per_frame, res)):
-                        return
-                    seq += 1
+                    self._stage(res, 'detect', seconds)
+                    if put(detected, (seq, per_frame, res)):
+                        seq += 1
+
+                if lookahead:
+                    self.detect_many(until_stopped(), emit)
+                else:
+                    for frames in until_stopped():
+                        t0 = time.perf_counter()
+                        per_frame = self.detect(frames)
+                        emit(per_frame, time.perf_counter() - t0)
             except BaseException as exc:    # noqa: B902 - re-raised below
                 put(built, (seq, exc))
             finally:

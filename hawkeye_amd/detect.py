@@ -8,6 +8,7 @@ Host-side mirror of the two OpenCV objects the reference's step 2 uses
 Frames and masks are PyTorch-ROCm uint8 tensors (plumbing only: device memory
 and the current HIP stream); all arithmetic happens in libhawkeye_hip.so.
 """
+import collections
 import os
 
 import numpy as np
@@ -288,6 +289,12 @@ class EventDetector:
                           for _ in range(self.DEPTH)]
         self._next = 0              # chunks submitted so far
         self._collected = 0         # chunks whose keypoints were returned
+        # set to a list to get every collected chunk there as (tag given to
+        # submit(), per-frame keypoints, (counts, rows)) instead of as
+        # submit()'s / flush()'s return value: for callers that keep chunks
+        # of several clips in flight (ClipScanner.detect_many)
+        self.collected = None
+        self._tags = collections.deque()
         # set to a list to collect (start, end, frames) event triples of the
         # MOG launches, recorded on the stream they run on
         # benchmarking: a list to which (start event, end event, frames) of
@@ -305,7 +312,7 @@ class EventDetector:
 
     DEPTH = int(os.environ.get('HK_DETECT_DEPTH', '3'))
 
-    def submit(self, frames):
+    def submit(self, frames, tag=None):
         t = frames.shape[0]
         if t == 0 or t > self.chunk:
             raise ValueError('chunk of {} frames (max {})'.format(t,
@@ -339,6 +346,7 @@ class EventDetector:
         else:
             self.blob[p].enqueue(masks, stream=self._side)
         self._next += 1
+        self._tags.append(tag)
         # keep DEPTH - 1 chunks in flight behind the one just launched
         while self._next - self._collected > self.DEPTH - 1:
             out += self._collect()
@@ -349,9 +357,13 @@ class EventDetector:
             return []
         p = self._collected % self.DEPTH
         self._collected += 1
+        tag = self._tags.popleft()
         out = self.blob[p].finish()
         if self.batches is not None:
             self.batches.append(self.blob[p].last_batch)
+        if self.collected is not None:
+            self.collected.append((tag, out, self.blob[p].last_batch))
+            return []
         return out
 
     def flush(self):
