@@ -159,31 +159,33 @@ def from_host_rate(scanner, spec, frames_dev, nframes, device):
                     'through hawkeye_amd.frames.PinnedHostSource'}
 
 
-def mog_alone_ms(scanner, frames):
-    """Average duration of full-chunk MOG launches over the clip with the
-    GPU to themselves, HIP events on the launch stream."""
+def mog_alone_ms(scanner, frames, size):
+    """Average duration of MOG launches of `size` frames (the pipeline's
+    chunk length) over the clip with the GPU to themselves, HIP events on the
+    launch stream."""
     det = scanner.detector
-    full = frames.shape[0] // CHUNK
+    size = max(1, min(CHUNK, int(round(size))))
+    full = frames.shape[0] // size
     if full == 0:
         return None
     det.mog.reset()
     masks = None
     if not det.use_tiles:
-        masks = torch.empty((CHUNK, frames.shape[1], frames.shape[2]),
+        masks = torch.empty((size, frames.shape[1], frames.shape[2]),
                             dtype=torch.uint8, device=frames.device)
 
     def launch(s):
         if det.use_tiles:
-            det.mog.apply_batch_tiles(frames[s:s + CHUNK], det._tiles[0])
+            det.mog.apply_batch_tiles(frames[s:s + size], det._tiles[0])
         else:
-            det.mog.apply_batch(frames[s:s + CHUNK], out=masks)
+            det.mog.apply_batch(frames[s:s + size], out=masks)
     launch(0)                                   # model and launch order set up
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for k in range(1, full):
-        launch(k * CHUNK)
+        launch(k * size)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / max(1, full - 1) if full > 1 else None
@@ -345,7 +347,8 @@ def run_clips(args, world, rank, local):
     # slowed the timed region by 15 %, tools/probe_batch_stages.py)
     scanner.detector.mog_timing = []
     scanner.detector.mog_timing_every = args.time_every
-    stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0}
+    stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0, 'step3_cpu': 0.0,
+               'step4_cpu': 0.0}
     barrier()
     t0 = time.perf_counter()
     for result in scanner.scan_many((frames for _ in range(args.steps)),
@@ -363,7 +366,8 @@ def run_clips(args, world, rank, local):
     # the same launches with nothing else on the GPU (no blob kernels of the
     # previous chunk in their way): the kernel's own duration, which is what
     # rocprofv3's kernel trace reports
-    alone_ms = mog_alone_ms(scanner, frames) if rank == 0 else None
+    alone_ms = mog_alone_ms(scanner, frames, launch_frames) \
+        if rank == 0 and launch_frames else None
 
     per_frame, arc_params = result.events, result.arc_params
     tags_left, tilt = int(result.alive.sum()), result.camera_tilt

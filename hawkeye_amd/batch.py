@@ -150,9 +150,7 @@ class ClipScanner:
         self._detect_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._detect_stream):
             det.mog.reset()
-            chunks = (self._from_source(frames) if hasattr(frames, 'read')
-                      else (frames[s:s + self.chunk]
-                            for s in range(0, frames.shape[0], self.chunk)))
+            chunks = self._chunks_of(frames)
             try:
                 for chunk in chunks:
                     out.extend(det.submit(chunk))
@@ -218,10 +216,7 @@ class ClipScanner:
                     torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._detect_stream):
                     det.mog.reset()
-                    chunks = (self._from_source(frames)
-                              if hasattr(frames, 'read') else
-                              (frames[s:s + self.chunk] for s in
-                               range(0, frames.shape[0], self.chunk)))
+                    chunks = self._chunks_of(frames)
                     for chunk in chunks:
                         det.submit(chunk, tag=state)
                         state['submitted'] += 1
@@ -247,6 +242,18 @@ class ClipScanner:
         finally:
             det.collected = None
 
+    def _chunks_of(self, frames):
+        """A clip as chunks of at most self.chunk frames.  A tensor is cut
+        into equal parts (1800 frames: 15 x 120, not 14 x 128 + 8): a short
+        last launch gives the GPU less to do than the host needs for a
+        chunk, and the queue runs dry at every clip's end."""
+        if hasattr(frames, 'read'):
+            return self._from_source(frames)
+        total = int(frames.shape[0])
+        parts = max(1, -(-total // self.chunk))
+        size = max(1, -(-total // parts))
+        return (frames[s:s + size] for s in range(0, total, size))
+
     def _from_source(self, src):
         while True:
             chunk = src.read(self.chunk)
@@ -264,6 +271,7 @@ class ClipScanner:
             em_stream = self._em_stream
         res = result if result is not None else ClipResult()
         t0 = time.perf_counter()
+        c0 = time.thread_time()
         res.events = per_frame
         res.frame_count = len(per_frame)
         res.frame, res.x, res.y, res.radius = events_to_soa(
@@ -279,11 +287,15 @@ class ClipScanner:
             clip.close()
             raise
         self._stage(res, 'step3', time.perf_counter() - t0)
+        # CPU time of the calling thread alone (helpers and step-3 worker
+        # threads not included): what a one-thread build costs its core
+        self._stage(res, 'step3_cpu', time.thread_time() - c0)
         return res, clip
 
     def refine_arcs(self, res, clip):
         """Step 4 and the read-back of its results; closes the clip."""
         t0 = time.perf_counter()
+        c0 = time.thread_time()
         try:
             clip.em_optimize()
             res.arc_params, res.arc_ids, res.arc_members = clip.arcs()
@@ -295,6 +307,7 @@ class ClipScanner:
         res.g_px_per_frame_sq = st['g_px_per_frame_sq']
         res.cm_per_pixel = st['cm_per_pixel']
         self._stage(res, 'step4', time.perf_counter() - t0)
+        self._stage(res, 'step4_cpu', time.thread_time() - c0)
         return res
 
     @staticmethod

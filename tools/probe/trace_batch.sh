@@ -6,6 +6,6 @@ OUT=$PWD/gpurun_out/trace_batch
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o b -- \
-    python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --host-frames 0 \
+    python3 bench.py --steps ${STEPS:-20} --warmup 2 --no-cpu-baseline --host-frames 0 \
     > "$OUT/bench.json" 2> "$OUT/err.txt" || exit 1
-python3 tools/probe/trace_gaps.py "$OUT"/b_kernel_trace.csv
+python3 tools/probe/trace_gaps.py "$OUT"/b_kernel_trace.csv 15

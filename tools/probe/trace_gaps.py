@@ -12,8 +12,12 @@ mog = [(a, b) for a, b, n in k if 'mog_batch2_k' in n]
 m = np.array(mog)
 dur = m[:, 1] - m[:, 0]
 gap = m[1:, 0] - m[:-1, 1]
-short = dur < 150
-print('MOG launches', len(m), 'duration pct 5/50/95', np.percentile(dur[~short], [5, 50, 95]))
+per_clip_launches = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if per_clip_launches:     # equal chunks: every n-th launch ends a clip
+    short = (np.arange(len(m)) % per_clip_launches) == per_clip_launches - 1
+else:                     # a short last launch ends a clip
+    short = dur < 150
+print('MOG launches', len(m), 'duration pct 5/50/95', np.percentile(dur, [5, 50, 95]))
 idx = np.where(short)[0]
 print('clips', len(idx))
 # the batch: the longest run of clip periods < 15 ms
@@ -43,3 +47,16 @@ for i in big[:200]:
         if s1 > a and s0 < e and 'mog_batch2_k' not in n:
             names[n[:50]] += 1
 print('large within-clip gaps:', len(big), names.most_common(8))
+
+# along the batch: per clip (launch groups), period, MOG time, gaps
+if per_clip_launches:
+    n = per_clip_launches
+    first = np.arange(0, len(m) - n, n)
+    print('clip  period  mog  gaps(within)  boundary   (ms)')
+    for c, i in enumerate(first):
+        period = m[i + n, 0] - m[i, 0]
+        if period > 30000:
+            print('  --- pause %.1f ms' % (period / 1e3)); continue
+        if c % 4 == 0:
+            print('%4d %7.2f %6.2f %7.2f %7.2f' % (c, period / 1e3, dur[i:i + n].sum() / 1e3,
+                  gap[i:i + n - 1].sum() / 1e3, gap[i + n - 1] / 1e3))
