@@ -829,9 +829,17 @@ __global__ __launch_bounds__(64) void blob_radius_k(
     const unsigned *__restrict__ ctr, unsigned cap_blob,
     BlobRec *__restrict__ recs, const ushort2 *__restrict__ pts,
     const ushort2 *__restrict__ tmp_pts, HostRec *__restrict__ hrecs,
-    unsigned *__restrict__ h_ctr) {
+    unsigned *__restrict__ h_ctr, unsigned *__restrict__ next_ctr,
+    unsigned next_words) {
     __shared__ double d2[MAXPTS];
     __shared__ double mid[2];
+    // The counters of this handle's next batch (its other set) start at
+    // zero: cleared here, by the last kernel of this batch, so that the next
+    // batch does not begin with a fill kernel that has to find wave slots
+    // among the MOG waves (160 us per chunk in a pipelined batch).
+    for (unsigned i = blockIdx.x * 64u + threadIdx.x; i < next_words;
+         i += gridDim.x * 64u)
+        next_ctr[i] = 0u;
     // hrecs and h_ctr are pinned host memory: what the host reads goes there
     // straight from this kernel (no copy kernels behind it, which would queue
     // for a slot beside the next chunk's MOG launch: 150 us per chunk).  The
@@ -1091,6 +1099,13 @@ struct hk_blob {
     HostRec *h_recs = nullptr;          // pinned, cap_blob entries; the
     HostRec *hrecs = nullptr;           // same memory as the device sees it,
     unsigned *h_ctr_dev = nullptr;      // and h_ctr likewise
+    // two sets of counters: `ctr` is the one the current (or last) batch
+    // uses, ctr_set[1 - ctr_at] the next batch's, cleared by this batch's
+    // radius kernel (ctr_clean) or, failing that, by a memset
+    unsigned *ctr_set[2] = {nullptr, nullptr};
+    bool ctr_clean[2] = {false, false};
+    int ctr_at = 0;
+    size_t ctr_words = 0;
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;
     int pending_frames = 0;             // batch between enqueue and finish
@@ -1131,7 +1146,8 @@ extern "C" int hk_blob_destroy(hk_blob *b) {
     if (!b) return HK_OK;
     hk::DeviceGuard guard(b->device);
     (void)hipFree(b->cands);
-    (void)hipFree(b->ctr);
+    (void)hipFree(b->ctr_set[0]);
+    (void)hipFree(b->ctr_set[1]);
     (void)hipFree(b->recs);
     (void)hipFree(b->pts);
     (void)hipFree(b->tmp_pts);
@@ -1219,9 +1235,12 @@ extern "C" int hk_blob_create(int width, int height, int max_frames,
 
     hipError_t e = hipMalloc((void **)&b->cands,
                              sizeof(Cand) * b->band_cap * nbuckets);
-    if (e == hipSuccess)        // counters, then one candidate count per band
-        e = hipMalloc((void **)&b->ctr,
-                      sizeof(unsigned) * (CTR_WORDS + nbuckets));
+    b->ctr_words = CTR_WORDS + nbuckets;
+    for (int k = 0; k < 2; ++k)     // counters, then a candidate count per band
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&b->ctr_set[k],
+                          sizeof(unsigned) * b->ctr_words);
+    b->ctr = b->ctr_set[0];
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)blob_trace_k,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1271,8 +1290,15 @@ static int launch_batch(hk_blob *b, int nframes) {
     const long frame_stride = b->frame_stride, pitch = b->pitch;
 
     const unsigned nbuckets = (unsigned)nframes * b->nbands * b->ncols;
-    HK_HIP(hipMemsetAsync(b->ctr, 0,
-                          sizeof(unsigned) * (CTR_WORDS + nbuckets), s));
+    // (the previous batch on this handle was finished before this one was
+    // enqueued, whatever stream it ran on)
+    const int at = 1 - b->ctr_at;
+    b->ctr_at = at;
+    b->ctr = b->ctr_set[at];
+    if (!b->ctr_clean[at])
+        HK_HIP(hipMemsetAsync(b->ctr, 0, sizeof(unsigned) * b->ctr_words, s));
+    b->ctr_clean[at] = false;
+    b->ctr_clean[1 - at] = false;
     if (!masks) {               // the MOG kernel's 1-bit tiles
         const int tiles_x = b->width / 32, tiles_y = b->height / 4;
         const long total = (long)nframes * tiles_x * tiles_y;
@@ -1329,8 +1355,10 @@ static int launch_batch(hk_blob *b, int nframes) {
     }();
     hipLaunchKernelGGL(blob_radius_k, dim3(radius_grid), dim3(64), 0, s, b->ctr,
                        b->cap_blob, b->recs, b->pts,
-                       (const ushort2 *)b->tmp_pts, b->hrecs, b->h_ctr_dev);
+                       (const ushort2 *)b->tmp_pts, b->hrecs, b->h_ctr_dev,
+                       b->ctr_set[1 - at], (unsigned)b->ctr_words);
     HK_LAUNCH_CHECK("blob_radius_k");
+    b->ctr_clean[1 - at] = true;
     HK_HIP(hipEventRecord(b->done, s));
     return HK_OK;
 }
