@@ -32,6 +32,8 @@ struct DeviceState {
     int *frame = nullptr;
     double *x = nullptr, *y = nullptr, *r = nullptr, *tw = nullptr;
     double *total = nullptr;            // [n] per-tag weight sums
+    char *h_tags = nullptr;             // pinned, tag_cap * 36 bytes: the
+                                        // tag arrays on their way up
     // per-launch arc tables (grown on demand)
     int arc_cap = 0;
     double *arc_params = nullptr;       // [arc_cap][8]

@@ -450,8 +450,13 @@ namespace hk {
 // (the latter synchronises the whole device) cost more than a whole EM pass
 // on a clip, so a released workspace is parked here, per device, and the next
 // clip on that device takes it over.  hk_release_cached_memory() frees them.
+// As many are kept as clips can be in steps 3-4 at a time in a pipelined batch
+// (one per builder thread, up to ~30 with more cores per GPU): with fewer, a
+// batch frees and allocates workspaces all the time, and every hipFree holds
+// up the detection thread's launches for milliseconds.  A workspace of a
+// 50 000-tag clip is a few MB.
 namespace {
-constexpr size_t POOL_MAX = 4;
+constexpr size_t POOL_MAX = 48;
 std::mutex g_pool_mutex;
 std::vector<DeviceState> g_pool;
 
@@ -459,6 +464,7 @@ void free_workspace(DeviceState &d) {
     DeviceGuard guard(d.device);
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
+    (void)hipHostFree(d.h_tags);
     (void)hipFree(d.arc_params); (void)hipFree(d.arc_win);
     (void)hipFree(d.arc_out); (void)hipFree(d.weights);
     (void)hipFree(d.bitmap); (void)hipFree(d.list); (void)hipFree(d.list_out);
@@ -474,8 +480,10 @@ int ensure_tag_capacity(DeviceState &d, int n) {
     const size_t cap = (size_t)std::max(2 * (long)n, 1L << 16);
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
+    (void)hipHostFree(d.h_tags);
     d.frame = nullptr;
     d.x = d.y = d.r = d.tw = d.total = nullptr;
+    d.h_tags = nullptr;
     d.tag_cap = 0;
     HK_HIP(dev_alloc(d.frame, cap));
     HK_HIP(dev_alloc(d.x, cap));
@@ -483,6 +491,7 @@ int ensure_tag_capacity(DeviceState &d, int n) {
     HK_HIP(dev_alloc(d.r, cap));
     HK_HIP(dev_alloc(d.tw, cap));
     HK_HIP(dev_alloc(d.total, cap));
+    HK_HIP(pin_alloc(d.h_tags, cap * (sizeof(int) + 4 * sizeof(double))));
     d.tag_cap = (int)cap;
     return HK_OK;
 }
@@ -509,19 +518,30 @@ int em_prepare(hk_clip &c, hipStream_t s) {
     if (rc != HK_OK) return rc;
     const size_t n = (size_t)c.n;
     if (n) {
-        HK_HIP(hipMemcpyAsync(d.frame, c.frame.data(), sizeof(int) * n,
+        // Through the workspace's pinned block: a copy from the clip's
+        // pageable vectors is a synchronous call of ~0.2 ms each that holds
+        // up other threads' launches (seen in a HIP API trace of a batch).
+        // The block is the workspace's own, and the workspace is not handed
+        // on before this clip's work on `s` has been waited for.
+        const size_t cap = (size_t)d.tag_cap;
+        double *hx = reinterpret_cast<double *>(d.h_tags);
+        double *hy = hx + cap, *hr = hy + cap, *htw = hr + cap;
+        int *hf = reinterpret_cast<int *>(htw + cap);
+        std::memcpy(hx, c.x.data(), sizeof(double) * n);
+        std::memcpy(hy, c.y.data(), sizeof(double) * n);
+        std::memcpy(hr, c.r.data(), sizeof(double) * n);
+        std::memcpy(htw, c.tw.data(), sizeof(double) * n);
+        std::memcpy(hf, c.frame.data(), sizeof(int) * n);
+        HK_HIP(hipMemcpyAsync(d.frame, hf, sizeof(int) * n,
                               hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.x, c.x.data(), sizeof(double) * n,
+        HK_HIP(hipMemcpyAsync(d.x, hx, sizeof(double) * n,
                               hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.y, c.y.data(), sizeof(double) * n,
+        HK_HIP(hipMemcpyAsync(d.y, hy, sizeof(double) * n,
                               hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.r, c.r.data(), sizeof(double) * n,
+        HK_HIP(hipMemcpyAsync(d.r, hr, sizeof(double) * n,
                               hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.tw, c.tw.data(), sizeof(double) * n,
+        HK_HIP(hipMemcpyAsync(d.tw, htw, sizeof(double) * n,
                               hipMemcpyHostToDevice, s));
-        // the sources are pageable vectors of the clip: make sure the copies
-        // have left them before anything can change
-        HK_HIP(hipStreamSynchronize(s));
     }
     d.ready = true;
     return HK_OK;

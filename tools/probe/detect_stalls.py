@@ -63,3 +63,20 @@ for name, v in cats.items():
           'max {:8.1f}   in calls > 300 us: {:6.1f} us/chunk'.format(
               name, len(v), v.sum() / chunks, *np.percentile(v, [50, 90, 99]),
               v.max(), v[v > 300].sum() / chunks))
+
+# cycles (MOG launch to MOG launch) that took much longer than a launch: where
+launches = [i for i in range(lo, hi) if log[i][0] == 'mog launch']
+late = []
+for a, b in zip(launches[:-1], launches[1:]):
+    cyc = log[b][1] - log[a][1]
+    if cyc > 0.0009:
+        parts = {}
+        for i in range(a, b):
+            parts[log[i][0]] = parts.get(log[i][0], 0) + log[i][2] - log[i][1]
+            parts['between'] = parts.get('between', 0) + log[i + 1][1] - log[i][2]
+        late.append((cyc, parts))
+print('cycles > 900 us: {} of {}, {:.1f} us per chunk in excess of 500'.format(
+    len(late), len(launches), sum(c - 0.0005 for c, _ in late) / len(launches) * 1e6))
+for cyc, parts in sorted(late, key=lambda r: -r[0])[:12]:
+    print('  {:7.0f} us: '.format(cyc * 1e6) + ', '.join(
+        '{} {:.0f}'.format(k, v * 1e6) for k, v in parts.items()))
