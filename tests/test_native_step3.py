@@ -232,3 +232,41 @@ def test_random_tag_sets_match_oracle():
             done += 1
     finally:
         em_ref.POWERS_AS_PRODUCTS = False
+
+
+def test_equal_heights_and_positions_keep_tag_order():
+    """Seeds are taken top of the frame first, tags of equal height in tag
+    order (reference tracker.py:486-488 sorts stably by y), and the per-frame
+    x index keeps equal x in tag order.  The native code orders the tags with
+    a radix sort on the bit patterns of y and insertion sorts on x: whole-pixel
+    coordinates (many ties), a shift that makes some of them negative, and
+    -0.0 beside 0.0 must give the oracle's arcs."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        'fuzz_arcs.py')
+    spec = importlib.util.spec_from_file_location('fuzz_arcs', path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from oracle import em_ref
+    try:
+        rng = np.random.RandomState(77)
+        done = 0
+        while done < 3:
+            case, meas = fz.random_case(rng)
+            total = sum(len(v) for v in meas.values())
+            if total > 1500 or total < 300:     # radix path, seconds of oracle
+                continue
+            shift = [0.0, 40.0, 300.0][done]
+            quant = {}
+            for f, tags in meas.items():
+                quant[f] = []
+                for t in tags:
+                    y = float(np.round(t[1] / 2.0) * 2.0) - shift
+                    if y == 0.0 and len(quant[f]) % 2:
+                        y = -0.0
+                    quant[f].append((float(np.round(t[0])), y) + tuple(t[2:]))
+            err = fz.compare(case, quant, False)
+            assert err is None, (err, case, shift)
+            done += 1
+    finally:
+        em_ref.POWERS_AS_PRODUCTS = False
