@@ -428,7 +428,9 @@ public:
         accepted_.store(0);
         accepting_.store(0);
         next_.store(0);
-        build_next_.store(maxcount <= 0 && has_vmax_ && nthreads_ > 1 &&
+        // (also for a one-thread build: same time on its own, and the
+        // threads that come to help find the lists made)
+        build_next_.store(maxcount <= 0 && has_vmax_ &&
                                   !getenv("HK_STEP3_LAZY_LISTS")
                               ? 0 : n_);
         commit_pos_.store(0);
