@@ -501,7 +501,9 @@ def run_segments(args, world, rank, local):
     first, keep, end = hkdist.segment_bounds(fcount, world, warmup)[rank]
     frame_bytes = spec['width'] * spec['height'] * 3
     total_mem = torch.cuda.get_device_properties(local).total_memory
-    resident = (end - first) * frame_bytes <= 0.72 * total_mem
+    # (a rehearsal with --share-gpu puts every rank's segment on the one GPU)
+    sharers = world if args.share_gpu else 1
+    resident = (end - first) * frame_bytes <= 0.72 * total_mem / sharers
     # all ranks take the same route, so that the line describes one thing
     if world > 1:
         flag = torch.tensor([1 if resident else 0], device=xdev)
