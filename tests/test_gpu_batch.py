@@ -54,6 +54,30 @@ def test_pipelined_batch_equals_clip_by_clip():
     sc.close()
 
 
+def test_ragged_and_empty_clips_with_and_without_lookahead():
+    """Clip lengths that are no multiple of the chunk (cut into equal parts),
+    shorter than a chunk, and zero: scan_many with the chunk pipeline kept
+    full across clips (the default) and drained at every clip's end gives
+    what scan() gives clip by clip."""
+    from hawkeye_amd.batch import ClipScanner
+    lengths = [70, 33, 0, 129, 1, 64]
+    clips = [render(small_spec(4250 + i, frames=max(n, 1)))[:n]
+             for i, n in enumerate(lengths)]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
+    assert [len(list(sc._chunks_of(c))) for c in clips] == [3, 2, 0, 5, 1, 2]
+    assert [int(p.shape[0]) for p in sc._chunks_of(clips[3])] == \
+        [26, 26, 26, 26, 25]
+    one_by_one = [sc.scan(c) for c in clips]
+    assert [len(r.events) for r in one_by_one] == lengths
+    for lookahead in (True, False):
+        batched = list(sc.scan_many(iter(clips), lookahead=lookahead))
+        assert len(batched) == len(clips)
+        for a, b in zip(one_by_one, batched):
+            same_result(a, b)
+    sc.close()
+
+
 def test_batch_stops_cleanly_when_the_consumer_stops():
     from hawkeye_amd.batch import ClipScanner
     clips = [render(small_spec(4200 + i, frames=80)) for i in range(4)]
