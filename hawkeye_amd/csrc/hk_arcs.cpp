@@ -1721,10 +1721,27 @@ int clean(hk_clip &c) {
     const double maxd = c.p.max_distance_pixels;
     const Rot rot = rotation(c);
     const size_t A = c.arcs.size();
-    // tag.weight keys, in arc-list order
-    std::vector<std::vector<int>> tag_arcs(c.n);
+    // tag.weight keys, in arc-list order: per tag the arcs that hold it (one
+    // flat list with offsets; most tags are on no arc at all)
+    std::vector<int> ta_off((size_t)c.n + 1, 0), ta;
     for (size_t k = 0; k < A; ++k)
-        for (int i : c.arcs[k].tags) tag_arcs[i].push_back((int)k);
+        for (int i : c.arcs[k].tags) ++ta_off[(size_t)i + 1];
+    for (int i = 0; i < c.n; ++i) ta_off[(size_t)i + 1] += ta_off[(size_t)i];
+    ta.resize((size_t)ta_off[(size_t)c.n]);
+    {
+        std::vector<int> at(ta_off.begin(), ta_off.end() - 1);
+        for (size_t k = 0; k < A; ++k)
+            for (int i : c.arcs[k].tags) ta[(size_t)at[(size_t)i]++] = (int)k;
+    }
+    struct ArcsOf {
+        const int *b, *e;
+        const int *begin() const { return b; }
+        const int *end() const { return e; }
+    };
+    auto tag_arcs = [&](int i) {
+        return ArcsOf{ta.data() + ta_off[(size_t)i],
+                      ta.data() + ta_off[(size_t)i + 1]};
+    };
     std::vector<char> tag_done(c.n, 0), arc_dead(A, 0), arc_done(A, 0);
 
     bool again = true;
@@ -1732,7 +1749,7 @@ int clean(hk_clip &c) {
         for (int i = 0; i < c.n; ++i) {
             if (!c.alive[i] || tag_done[i]) continue;
             bool good = false;
-            for (int k : tag_arcs[i])
+            for (int k : tag_arcs(i))
                 if (!arc_dead[k] &&
                     arc_tag_distance(c, c.arcs[k], rot, i) < maxd) {
                     good = true;
@@ -1743,7 +1760,7 @@ int clean(hk_clip &c) {
                 continue;
             }
             c.alive[i] = 0;
-            for (int k : tag_arcs[i]) {
+            for (int k : tag_arcs(i)) {
                 if (arc_dead[k]) continue;
                 std::vector<int> &tg = c.arcs[k].tags;
                 const auto it = std::lower_bound(tg.begin(), tg.end(), i);
@@ -1782,7 +1799,7 @@ int clean(hk_clip &c) {
         if (!c.alive[i]) continue;
         int best = -1;
         double best_d = 0;
-        for (int k : tag_arcs[i]) {
+        for (int k : tag_arcs(i)) {
             if (arc_dead[k]) continue;
             const double d = arc_tag_distance(c, c.arcs[k], rot, i);
             if (best < 0 || d < best_d) {
