@@ -218,7 +218,8 @@ def mog_roofline(launch_ms, alone_ms, launch_frames, px, scene):
             'achieved': None, 'peak': round(peak, 1),
             'unit': 'G wave-instructions/s (VALU)', 'frac': None,
             'traffic': None}
-    scale = launch_frames / 128.0
+    # the counters are per profiled launch; the kernel's work is per frame
+    scale = launch_frames / float((issue or {}).get('frames_per_launch', 128))
     if counts is not None:
         # quad-cycle issue slots: one per VALU instruction, two for the few
         # transcendental ones (SQ_ACTIVE_INST_VALU counts exactly that)

@@ -18,6 +18,9 @@ streams) into the committed summaries under profiles/:
                                       MI355X_MICROARCH.md, HBM section)
 
     python3 tools/mog_profile_summary.py r02 [sq_dir_tag] [ubench_dir_tag]
+
+HK_PROF_CHUNK = frames per launch the passes were taken with (120: what the
+pipeline launches for a 1800-frame clip; tools/prof_mog_sq.sh's default).
 """
 import collections
 import csv
@@ -36,7 +39,7 @@ SIMDS = 1024                    # 256 CUs x 4
 XCDS = 8                        # GRBM_GUI_ACTIVE is summed over the XCDs
 PX = 1920 * 1080
 WAVE_PIXELS = 128               # 64 lanes x 2 pixels
-FRAMES = 128
+FRAMES = int(os.environ.get('HK_PROF_CHUNK', '120'))   # frames per profiled launch
 os.makedirs('profiles', exist_ok=True)
 
 

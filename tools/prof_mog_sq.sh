@@ -6,6 +6,7 @@
 # combined with a trace mode.
 set -o pipefail
 TAG=${1:-r02}
+CHUNK=${HK_PROF_CHUNK:-120}     # frames per launch: what the pipeline uses on a 1800-frame clip
 OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -19,11 +20,11 @@ for scene in static clip; do
   i=0
   # the benchmark clip is profiled over all of its full launches (the mix of
   # update paths changes along the clip), the static scene over four
-  if [ $scene = clip ]; then FRAMES=1792; else FRAMES=512; fi
+  if [ $scene = clip ]; then FRAMES=$((1800 / CHUNK * CHUNK)); else FRAMES=$((4 * CHUNK)); fi
   for pass in "$P1" "$P2" "$P3" "$P4" "$P5"; do
     i=$((i+1))
     timeout -s KILL 150 rocprofv3 --pmc $pass --output-format csv \
-        -d "$OUT/${scene}_p$i" -o pmc -- python3 tools/mog_prof.py --scene $scene --frames $FRAMES --reps 1 \
+        -d "$OUT/${scene}_p$i" -o pmc -- python3 tools/mog_prof.py --scene $scene --frames $FRAMES --chunk $CHUNK --reps 1 \
         > "$OUT/${scene}_p$i.log" 2> "$OUT/${scene}_p$i.err" || { echo "pass $scene $i failed"; tail -5 "$OUT/${scene}_p$i.err"; exit 1; }
   done
 done
