@@ -28,6 +28,9 @@ if os.environ.get('PROBE_SET_DEVICE'):
     torch.cuda.set_device(0)
 if os.environ.get('PROBE_MOG_TIMING'):
     sc.detector.mog_timing = []
+for _ in range(int(os.environ.get('PROBE_WARM_BATCHES', '0'))):
+    for r in sc.scan_many((frames for _ in range(n)), count=n):
+        pass
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 rows = []
@@ -39,6 +42,7 @@ print('{} clips in {:.1f} ms = {:.0f} frames/s'.format(
 import statistics
 print('median detect {:.2f} ms'.format(statistics.median(s['detect'] for _, s in rows) * 1e3))
 for k, (t, s) in enumerate(rows if os.environ.get('PROBE_ROWS') else []):
-    print('clip {:2d} delivered at {:7.1f} ms  detect {:5.1f}  step3 {:6.1f}  '
-          'step4 {:5.1f}'.format(k, t * 1e3, s['detect'] * 1e3,
-                                 s['step3'] * 1e3, s['step4'] * 1e3))
+    print('clip {:2d} delivered at {:7.1f} ms  detect {:5.1f}  step3 {:6.1f} (cpu {:5.1f})  '
+          'step4 {:5.1f} (cpu {:4.1f})'.format(k, t * 1e3, s['detect'] * 1e3,
+                                 s['step3'] * 1e3, s['step3_cpu'] * 1e3,
+                                 s['step4'] * 1e3, s['step4_cpu'] * 1e3))
