@@ -601,7 +601,6 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     // every load is an HBM miss (~2 us under load): the frames of the next
     // group of DEPTH are requested while this group is processed, and so are
     // their learning rates.
-    const uint8_t *src = bgr + i0 * 3;
     uint8_t *dst = mask + i0;
     unsigned cur[DEPTH][2], nxt[DEPTH][2];
     float cur_alpha[DEPTH], nxt_alpha[DEPTH];
@@ -611,18 +610,49 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     // the end of the last frame: that one takes three 2-byte loads.
     const bool last_wave =
         __builtin_amdgcn_ballot_w64(i0 + 2 >= n_pixels) != 0;
-    auto fetch = [&](int f, unsigned (&d)[2]) {
-        const uint8_t *p = src + (long)f * bgr_frame_stride;
+    // The loads go through a buffer descriptor per group of frames: the
+    // group's base lives in scalar registers, the frame within the group is
+    // a scalar offset and the lane's pair a 32-bit vector offset that never
+    // changes, so a load costs no vector address arithmetic (a 64-bit vector
+    // multiply-add per frame before).  The host checks that DEPTH frames
+    // span less than 4 GB.
+    // Odd lanes load from 2 bytes before their pair: every load is 4-byte
+    // aligned when the frames are, and none reaches beyond the wave's own row
+    // segments into a cache line of the neighbouring group.  decode() shifts
+    // the two surplus bytes out.
+    const unsigned sh = last_wave ? 0u : (lane & 1) * 16u;
+    const int src_off = (int)(i0 * 3) - (int)(sh >> 3);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    auto fetch_group = [&](int t, unsigned (&d)[DEPTH][2]) {
+        // frames t .. t + DEPTH - 1; past the end of the batch the last
+        // whole group is read again (nobody looks at the result)
+        if (t + DEPTH > nframes) t = nframes >= DEPTH ? nframes - DEPTH : 0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t *>(bgr + (long)t * bgr_frame_stride), 0, -1,
+            0x00020000);
+        // (the host launches this kernel with nframes >= DEPTH)
         if (!last_wave) {
-            typedef unsigned u2a __attribute__((ext_vector_type(2), aligned(2)));
-            const u2a v = *reinterpret_cast<const u2a *>(p);
-            d[0] = v.x;
-            d[1] = v.y;
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const u2 v = __builtin_bit_cast(
+                    u2, __builtin_amdgcn_raw_buffer_load_b64(
+                            rsrc, src_off, (int)(j * bgr_frame_stride), 0));
+                d[j][0] = v.x;
+                d[j][1] = v.y;
+            }
         } else {
-            const unsigned short *s16 =
-                reinterpret_cast<const unsigned short *>(p);
-            d[0] = s16[0] | ((unsigned)s16[1] << 16);
-            d[1] = s16[2];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const int so = (int)(j * bgr_frame_stride);
+                const unsigned a = __builtin_amdgcn_raw_buffer_load_b16(
+                    rsrc, src_off, so, 0);
+                const unsigned b = __builtin_amdgcn_raw_buffer_load_b16(
+                    rsrc, src_off + 2, so, 0);
+                const unsigned e = __builtin_amdgcn_raw_buffer_load_b16(
+                    rsrc, src_off + 4, so, 0);
+                d[j][0] = a | (b << 16);
+                d[j][1] = e;
+            }
         }
     };
     auto alphas_of = [&](int t, float (&a)[DEPTH]) {
@@ -631,19 +661,16 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) a[j] = alpha_table[i + j];
     };
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) fetch(j < nframes ? j : nframes - 1, cur[j]);
+    fetch_group(0, cur);
     alphas_of(0, cur_alpha);
     for (int t0 = 0; t0 < nframes; t0 += DEPTH) {
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int f = t0 + DEPTH + j;
-            fetch(f < nframes ? f : nframes - 1, nxt[j]);
-        }
+        fetch_group(t0 + DEPTH, nxt);
         alphas_of(t0 + DEPTH, nxt_alpha);
         // frame j of the group as three pairs of floats
         auto decode = [&](int j, f2 &x0, f2 &x1, f2 &x2) {
-            const unsigned c01 = cur[j][0], c2 = cur[j][1];
+            const unsigned c01 =
+                __builtin_amdgcn_alignbit(cur[j][1], cur[j][0], sh);
+            const unsigned c2 = cur[j][1] >> sh;
             // bytes b0 g0 r0 b1 | g1 r1 (and two of the next pair)
             x0.x = (float)(c01 & 255u);
             x1.x = (float)((c01 >> 8) & 255u);
@@ -1096,6 +1123,7 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
     int frames_before = m.frames_before;
     const bool fast =
         bgr_pitch == 3L * m.width && mask_pitch == m.width && N % 2 == 0 &&
+        3 * N < (1L << 31) && (nframes == 1 || bgr_frame_stride < (1L << 29)) &&
         ((uintptr_t)bgr_dev & 1) == 0 && ((uintptr_t)mask_dev & 1) == 0 &&
         (nframes == 1 ||
          (bgr_frame_stride % 2 == 0 && mask_frame_stride % 2 == 0));
