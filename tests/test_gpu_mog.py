@@ -117,6 +117,29 @@ def test_pitched_input_and_reset():
     assert np.array_equal(again, want)
 
 
+@pytest.mark.parametrize('gap', [
+    3 * 56 * 3,             # dense rows, frames apart: the batch kernel's
+                            # scalar frame offsets are not multiples of a frame
+    (1 << 29) + 64,         # too far apart for them: the frame-at-a-time path
+    3 * 56 * 3 + 1,         # odd frame stride: not 2-byte aligned, same path
+])
+def test_frames_apart_in_memory(gap):
+    from hawkeye_amd.detect import BackgroundSubtractorMOG
+    h, w, t = 40, 56, 14
+    rng = np.random.RandomState(21)
+    frames = frames_moving_discs(rng, t, h, w)
+    want, want_model = run_oracle(frames)
+    stride = h * w * 3 + gap if gap < (1 << 29) else gap
+    flat = torch.zeros(stride * t, dtype=torch.uint8, device='cuda')
+    view = flat.as_strided((t, h, w, 3), (stride, w * 3, 3, 1))
+    view.copy_(torch.from_numpy(frames).cuda())
+    mog = BackgroundSubtractorMOG(w, h)
+    got = mog.apply_batch(view).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(mog.export_model().view(np.uint32),
+                          want_model.view(np.uint32))
+
+
 def test_full_hd_round_trip_properties():
     """At BASELINE size (1920x1080) the oracle is too slow to run per frame in
     a test, so check size-independent properties: a static scene goes fully
