@@ -413,6 +413,7 @@ def run_clips(args, world, rank, local):
                    'detect_chunk_frames': CHUNK},
         'host_cores_per_rank': host_core_share(),
         'builders': builders, 'step3_threads_per_clip': host_threads,
+        'detect_lanes': int(os.environ.get('HK_DETECT_LANES', '1')),
         'untimed_preroll': {'seconds': round(preroll_s, 2),
                             'pipelined_clips': preroll_clips,
                             'single_clip_scans': args.warmup + 3},

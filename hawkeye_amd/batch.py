@@ -125,6 +125,22 @@ class ClipScanner:
         dev = torch.device('cuda', self.device)
         self._detect_stream = torch.cuda.Stream(device=dev)
         self._em_stream = torch.cuda.Stream(device=dev)
+        # detection lanes: (detector, stream); lane 0 is the scanner's own,
+        # scan_many's further detection threads get theirs on first use
+        self._lanes = [(self._det, self._detect_stream)]
+        self._lanes_lock = threading.Lock()
+
+    def _lane(self, i):
+        with self._lanes_lock:
+            while len(self._lanes) <= i:
+                det = EventDetector(
+                    self.width, self.height,
+                    blob_params=hawkeye_blob_params(self.height),
+                    chunk=self.chunk, device=self.device)
+                stream = torch.cuda.Stream(
+                    device=torch.device('cuda', self.device))
+                self._lanes.append((det, stream))
+            return self._lanes[i]
 
     @property
     def detector(self):
@@ -134,6 +150,9 @@ class ClipScanner:
         det, self._det = getattr(self, '_det', None), None
         if det is not None:
             det.close()
+        lanes, self._lanes = getattr(self, '_lanes', None) or [], []
+        for other, _ in lanes[1:]:
+            other.close()
 
     __del__ = close
 
@@ -167,7 +186,7 @@ class ClipScanner:
         assert len(out.counts) == len(out)
         return out
 
-    def detect_many(self, clips, emit):
+    def detect_many(self, clips, emit, lane=0):
         """Step 2 of one clip after the other without draining the chunk
         pipeline in between: the first MOG launches of a clip are queued
         while the blob kernels and the host-side finish of the previous
@@ -177,8 +196,10 @@ class ClipScanner:
         time the clip added to the stream of results.  Same events as
         detect() clip by clip.  The next clip is taken from `clips` before
         the previous one's last chunks are collected: an iterator that takes
-        long to produce a clip delays those results by that time."""
-        det = self._det
+        long to produce a clip delays those results by that time.
+        `lane`: which detector and stream to use (0 = the scanner's own; see
+        scan_many)."""
+        det, detect_stream = self._lane(lane)
         det.collected = []
         open_clips = collections.deque()
         last_done = [time.perf_counter()]
@@ -212,9 +233,9 @@ class ClipScanner:
                          'collected': 0, 'closed': False,
                          't0': time.perf_counter()}
                 open_clips.append(state)
-                self._detect_stream.wait_stream(
+                detect_stream.wait_stream(
                     torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._detect_stream):
+                with torch.cuda.stream(detect_stream):
                     det.mog.reset()
                     chunks = self._chunks_of(frames)
                     for chunk in chunks:
@@ -224,7 +245,7 @@ class ClipScanner:
                             drain()
                 state['closed'] = True
                 drain()
-            with torch.cuda.stream(self._detect_stream):
+            with torch.cuda.stream(detect_stream):
                 det.flush()
             drain()
         except BaseException:
@@ -233,7 +254,7 @@ class ClipScanner:
             try:
                 if open_clips:
                     open_clips.pop()            # the clip that failed
-                with torch.cuda.stream(self._detect_stream):
+                with torch.cuda.stream(detect_stream):
                     det.flush()
                 drain()
             except Exception:       # noqa: BLE001 - the first error counts
@@ -349,7 +370,15 @@ class ClipScanner:
         tensors / sources of this scanner's size), in order.  Detection of
         later clips (GPU, one worker thread) runs beside steps 3-4 of earlier
         ones (`builders` threads, a clip each; step 3 on `host_threads` worker
-        threads per clip).  `count` = number of clips if `clips` cannot tell
+        threads per clip).  With lookahead, detection can run on
+        `HK_DETECT_LANES` threads, each with a detector and a stream of its
+        own, taking clips in turn: a MOG launch ends with a tail of slow
+        waves that leaves part of the chip idle, and the other lane's launch
+        fills it (tools/probe/two_detectors.py, detection only: 7.7 ms per
+        clip with one lane, 6.2-7.2 with two).  The default is one lane: with
+        16 host cores per GPU the builders bound a batch, not detection, and
+        a second lane gains nothing (60-clip batch 164-171 k frames/s with
+        one lane, 164-165 k with two); with more cores per GPU set 2.  `count` = number of clips if `clips` cannot tell
         (a generator); unused today, kept for callers that pass it.
         `lookahead` (default on): detection starts on the next clip before
         the last chunks of the previous one are collected (detect_many)."""
@@ -362,6 +391,11 @@ class ClipScanner:
         elif builders is None:
             builders = max(1, (host_core_share() - 1) // int(host_threads))
         builders = max(1, int(builders))
+        lanes = 1
+        if lookahead:
+            lanes = max(1, int(os.environ.get('HK_DETECT_LANES', '1')))
+            if count is not None:
+                lanes = max(1, min(lanes, int(count)))
         detected = queue.Queue(maxsize=builders)
         built = queue.Queue(maxsize=builders)
         stop = threading.Event()
@@ -384,36 +418,62 @@ class ClipScanner:
                     pass
             return END
 
-        def detect_stage():
-            seq = 0
+        source = iter(clips)
+        src_lock = threading.Lock()
+        next_seq = [0]
+        live = [lanes]
+        failed = [False]
+
+        def detect_stage(lane):
+            mine = collections.deque()  # this lane's clips not yet delivered
             try:
                 torch.cuda.set_device(self.device)
 
                 def until_stopped():
-                    for frames in clips:
-                        if stop.is_set():
-                            return
+                    while True:
+                        with src_lock:
+                            if stop.is_set() or failed[0]:
+                                return
+                            try:
+                                frames = next(source)
+                            except StopIteration:
+                                return
+                            mine.append(next_seq[0])
+                            next_seq[0] += 1
                         yield frames
 
                 def emit(per_frame, seconds):
-                    nonlocal seq
                     res = ClipResult()
                     self._stage(res, 'detect', seconds)
-                    if put(detected, (seq, per_frame, res)):
-                        seq += 1
+                    if put(detected, (mine[0], per_frame, res)):
+                        mine.popleft()
 
                 if lookahead:
-                    self.detect_many(until_stopped(), emit)
+                    self.detect_many(until_stopped(), emit, lane)
                 else:
                     for frames in until_stopped():
                         t0 = time.perf_counter()
                         per_frame = self.detect(frames)
                         emit(per_frame, time.perf_counter() - t0)
             except BaseException as exc:    # noqa: B902 - re-raised below
-                put(built, (seq, exc))
+                # reported at the oldest clip this lane still owes (the one
+                # that failed, or one before it that is lost with it); the
+                # other lanes take no further clips
+                with src_lock:
+                    failed[0] = True
+                    if mine:
+                        at = mine[0]
+                    else:
+                        at = next_seq[0]
+                        next_seq[0] += 1
+                put(built, (at, exc))
             finally:
-                for _ in range(builders):
-                    put(detected, END)
+                with src_lock:
+                    live[0] -= 1
+                    last = live[0] == 0
+                if last:
+                    for _ in range(builders):
+                        put(detected, END)
 
         # A builder thread with no clip of its own helps the step-3 builds
         # the other threads are running (hk_step3_help: it runs seeds ahead
@@ -487,7 +547,8 @@ class ClipScanner:
         if host_threads is None:    # builders given: share the cores out
             host_threads = max(1, (host_core_share() - 1) // builders)
         nat.check(nat.lib.hk_set_host_threads(int(host_threads)))
-        workers = [threading.Thread(target=detect_stage, daemon=True)] + \
+        workers = [threading.Thread(target=detect_stage, args=(lane,),
+                                    daemon=True) for lane in range(lanes)] + \
             [threading.Thread(target=build_stage, daemon=True)
              for _ in range(builders)]
         for w in workers:

@@ -36,8 +36,10 @@ def same_result(a, b):
     assert a.camera_tilt == b.camera_tilt
 
 
-def test_pipelined_batch_equals_clip_by_clip():
+@pytest.mark.parametrize('lanes', [1, 2, 3])
+def test_pipelined_batch_equals_clip_by_clip(lanes, monkeypatch):
     from hawkeye_amd.batch import ClipScanner
+    monkeypatch.setenv('HK_DETECT_LANES', str(lanes))
     specs = [small_spec(4100 + i, balls=3 + i % 3) for i in range(5)]
     clips = [render(s) for s in specs]
     torch.cuda.synchronize()
@@ -54,12 +56,14 @@ def test_pipelined_batch_equals_clip_by_clip():
     sc.close()
 
 
-def test_ragged_and_empty_clips_with_and_without_lookahead():
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_ragged_and_empty_clips_with_and_without_lookahead(lanes, monkeypatch):
     """Clip lengths that are no multiple of the chunk (cut into equal parts),
     shorter than a chunk, and zero: scan_many with the chunk pipeline kept
     full across clips (the default) and drained at every clip's end gives
     what scan() gives clip by clip."""
     from hawkeye_amd.batch import ClipScanner
+    monkeypatch.setenv('HK_DETECT_LANES', str(lanes))
     lengths = [70, 33, 0, 129, 1, 64]
     clips = [render(small_spec(4250 + i, frames=max(n, 1)))[:n]
              for i, n in enumerate(lengths)]
@@ -78,8 +82,10 @@ def test_ragged_and_empty_clips_with_and_without_lookahead():
     sc.close()
 
 
-def test_batch_stops_cleanly_when_the_consumer_stops():
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_batch_stops_cleanly_when_the_consumer_stops(lanes, monkeypatch):
     from hawkeye_amd.batch import ClipScanner
+    monkeypatch.setenv('HK_DETECT_LANES', str(lanes))
     clips = [render(small_spec(4200 + i, frames=80)) for i in range(4)]
     torch.cuda.synchronize()
     sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
@@ -91,8 +97,10 @@ def test_batch_stops_cleanly_when_the_consumer_stops():
     sc.close()
 
 
-def test_errors_in_a_stage_reach_the_caller():
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_errors_in_a_stage_reach_the_caller(lanes, monkeypatch):
     from hawkeye_amd.batch import ClipScanner
+    monkeypatch.setenv('HK_DETECT_LANES', str(lanes))
     good = render(small_spec(4300, frames=60))
     bad = torch.zeros((10, 100, 100, 3), dtype=torch.uint8, device='cuda')
     torch.cuda.synchronize()
