@@ -1079,7 +1079,7 @@ private:
                 if (s.taken[g] != s.stamp)
                     for (int q = 0; q < k; ++q)
                         if (p[2 * q + 1] >= pos)
-                            add_one_to_frontier(p[2 * q], pos, s, res);
+                            add_listed_to_frontier(p[2 * q], g, s, res);
                 p += 2 * k;
             }
             return;
@@ -1096,6 +1096,29 @@ private:
     void add_range_to_frontier(int j0, int j1, int pos, Scratch &s,
                                SeedResult &res) {
         for (int j = j0; j < j1; ++j) add_one_to_frontier(j, pos, s, res);
+    }
+
+    // A tag of a grouped neighbour list: its frame g is not taken and its
+    // queue position is not before the seed's (both checked by the caller).
+    // Most such tags are in the frontier already -- a new member's neighbours
+    // are largely those of the members before it -- and that is decided on
+    // the thread's own marks, before the tag's record and its done flag
+    // (shared with the other threads) are touched.  A tag in the frontier
+    // was consulted when it was added.
+    void add_listed_to_frontier(int j, int g, Scratch &s, SeedResult &res) {
+        Scratch::Marks &m = s.marks[(size_t)j];
+        if (m.in_frontier == s.stamp) return;
+        if (done_[j].load(std::memory_order_relaxed)) return;
+        if (m.seen != s.run_stamp) {
+            m.seen = s.run_stamp;
+            res.consulted.push_back(j);
+        }
+        m.in_frontier = s.stamp;
+        const TagRec &t = tag_[(size_t)j];
+        s.frontier.push_back(j);
+        s.ff.push_back((double)g);
+        s.fx.push_back(t.x);
+        s.fy.push_back(t.y);
     }
 
     void add_one_to_frontier(int j, int pos, Scratch &s, SeedResult &res) {
