@@ -1192,7 +1192,7 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
         if (tiles_dev)
             return hk::fail(HK_ERR_ARG,
                             "hk_mog_apply_batch_tiles: needs densely packed, "
-                            "2-byte aligned frames");
+                            "2-byte aligned frames less than 512 MB apart");
         const unsigned blocks = (unsigned)((N + 255) / 256);
         hipLaunchKernelGGL(mog_batch1_k, dim3(blocks), dim3(256), 0, s,
                            m.planes, N, m.width, (const uint8_t *)bgr_dev,

@@ -95,7 +95,8 @@ int hk_mog_apply_batch(hk_mog *m, const void *bgr_dev, long bgr_frame_stride,
  * 32-bit words, the bits of the tile's even pixels (16 per row, rows 0-3) and
  * then of its odd pixels.  Same model update, same mask bits as
  * hk_mog_apply_batch.  Needs width % 32 == 0, height % 4 == 0
- * (hk_mog_tiles_supported) and densely packed frames (bgr_pitch == 3*width);
+ * (hk_mog_tiles_supported) and densely packed, 2-byte aligned frames
+ * (bgr_pitch == 3*width) less than 512 MB apart (bgr_frame_stride);
  * tiles_dev 16-byte aligned, frame t at tiles_dev + t * (W/32)*(H/4)*4 words.
  * No counterpart in the reference (its fgmask is a byte image,
  * tracker.py:395). */
