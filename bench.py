@@ -5,6 +5,11 @@ Benchmark of the hot path: step 2 detection (MOG + blob detector) and steps
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--layout clips|segments]
 
+With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) the command
+starts its N ranks itself (torch.distributed.run as a child process; the
+parent touches no GPU) and relays rank 0's JSON line; under
+`python -m torch.distributed.run ... bench.py --gpus N` it is a rank.
+
 --layout clips (default).  One "step" = one whole clip through detect ->
 build_initial_arcs -> EM_optimize, frames already resident in HBM (rendered on
 the device before the timed region).  Workload = BASELINE.json configs[2], the
@@ -62,12 +67,41 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import torch                                    # noqa: E402
-import torch.distributed as dist                # noqa: E402
+# torch and the package are imported by load_runtime(), after main() has
+# decided whether this process is a rank or only the parent that starts the
+# ranks: the parent of a multi-GPU run never loads them and never touches a GPU
+torch = dist = hkdist = synth = ClipScanner = host_core_share = None
 
-from hawkeye_amd import dist as hkdist          # noqa: E402
-from hawkeye_amd import synth                   # noqa: E402
-from hawkeye_amd.batch import ClipScanner, host_core_share  # noqa: E402
+
+def load_runtime():
+    global torch, dist, hkdist, synth, ClipScanner, host_core_share
+    import torch as _torch
+    import torch.distributed as _dist
+    from hawkeye_amd import dist as _hkdist
+    from hawkeye_amd import synth as _synth
+    from hawkeye_amd.batch import ClipScanner as _scanner
+    from hawkeye_amd.batch import host_core_share as _share
+    torch, dist, hkdist, synth = _torch, _dist, _hkdist, _synth
+    ClipScanner, host_core_share = _scanner, _share
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started on its own: run the N ranks as
+    children (torch.distributed.run, one process per GPU, rendezvous on
+    127.0.0.1), let rank 0's JSON line through on stdout and return their exit
+    status.  This parent holds no GPU state (nothing here imports torch)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
 
 WORKLOAD = 'C_1080p60_9ball_noisy'
 SEGMENT_WORKLOAD = 'D_4k240_9ball_long'
@@ -659,6 +693,9 @@ def main():
     ap.add_argument('--share-gpu', action='store_true',
                     help='every rank uses GPU 0 (rehearsal on a one-GPU box; '
                          'the numbers mean nothing)')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='start the ranks, form the process group, report its '
+                         'size and stop before any GPU work (tests)')
     ap.add_argument('--cpu-sample', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=None,
@@ -674,17 +711,26 @@ def main():
     if args.steps is None:
         args.steps = 60 if args.layout == 'clips' else 3
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # not under a launcher: be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus {} must be launched with '
-                     'torch.distributed.run --nproc-per-node {}'.format(
-                         args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    load_runtime()
     if args.share_gpu:      # rehearsal of the N > 1 control flow on one GPU
         local = 0
+    if args.rendezvous_only:
+        dist.init_process_group(args.backend)
+        seen = torch.tensor([1])
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({'rendezvous': int(seen.item()),
+                              'world_size': dist.get_world_size(),
+                              'backend': args.backend}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     if world > 1:
         if args.backend == 'nccl':
@@ -696,6 +742,10 @@ def main():
     run = run_clips if args.layout == 'clips' else run_segments
     out = run(args, world, rank, local)
     if out is not None:
+        # how many ranks the collective backend itself saw (RCCL for 'nccl')
+        out['ranks_in_process_group'] = dist.get_world_size() \
+            if dist.is_initialized() else 1
+        out['backend'] = args.backend if world > 1 else None
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

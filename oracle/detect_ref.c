@@ -94,6 +94,18 @@ const float *hkref_mog_model(void *h)
     return (const float *)((MogRef *)h)->model;
 }
 
+/* Test hook: continue from a given state (model in MixData order,
+ * [height*width][MOG_K][8] floats, and the number of frames it has seen), so
+ * that a window deep inside a long clip can be checked without the oracle
+ * running the thousand frames before it. */
+void hkref_mog_set_state(void *h, const float *model, int nframes)
+{
+    MogRef *m = (MogRef *)h;
+    memcpy(m->model, model,
+           (size_t)m->width * m->height * MOG_K * sizeof(MixData));
+    m->nframes = nframes;
+}
+
 /* Learning rate used for frame number n (1-based) when the caller passes
  * learningRate < 0, which is what the Python binding's apply(frame) does. */
 float hkref_mog_alpha(int nframes)

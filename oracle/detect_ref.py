@@ -43,6 +43,7 @@ def lib():
         L.hkref_mog_nframes.argtypes = [C.c_void_p]
         L.hkref_mog_model.restype = C.POINTER(C.c_float)
         L.hkref_mog_model.argtypes = [C.c_void_p]
+        L.hkref_mog_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.hkref_mog_alpha.restype = C.c_float
         L.hkref_mog_alpha.argtypes = [C.c_int]
         L.hkref_find_contours.argtypes = [
@@ -88,6 +89,13 @@ class Mog:
         n = self.h * self.w * self.K * 8
         return np.ctypeslib.as_array(p, (n,)).reshape(
             self.h * self.w, self.K, 8).copy()
+
+    def set_state(self, model, nframes):
+        """Continue from `model` (as model() returns it) after `nframes`
+        frames."""
+        model = np.ascontiguousarray(model, np.float32)
+        assert model.size == self.h * self.w * self.K * 8
+        lib().hkref_mog_set_state(self._h, model.ctypes.data, int(nframes))
 
     def __del__(self):
         if getattr(self, '_h', None):

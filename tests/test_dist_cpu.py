@@ -114,3 +114,41 @@ def test_host_core_share_and_stage_plan(monkeypatch):
         for cores in (1, 2, 3, 8, 16):
             b, t = plan(count, cores=cores)
             assert b >= 1 and t >= 1 and b * t <= max(1, cores - 1)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it: the parent
+    starts two ranks (torch.distributed.run), they form the process group
+    (gloo here: no GPU) and rank 0's line comes back on the parent's stdout
+    (reference: none -- the reference has no distributed layer)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT')}
+    out = subprocess.run(
+        [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2',
+         '--backend', 'gloo', '--share-gpu', '--rendezvous-only'],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    got = json.loads(lines[0])
+    assert got == {'rendezvous': 2, 'world_size': 2, 'backend': 'gloo'}
+
+
+def test_bench_parent_exits_with_the_ranks_status():
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run(
+        [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2',
+         '--backend', 'no-such-backend', '--rendezvous-only'],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0

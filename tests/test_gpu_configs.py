@@ -5,9 +5,12 @@ against the C oracle on the same rendered frames (step 2, bit for bit, on as
 many frames as the oracle does in seconds) and through size-independent
 properties on the whole clips: batch = clip by clip, 1-bit tile path = byte
 path, the recovered arcs are the rendered flights.  Reference loop covered:
-tracker.py:382-433.  (Configuration C is what bench.py runs and re-checks
-against the oracle on every run; configs[0] needs a video file and cv2.)
+tracker.py:382-433.  Configuration C (the one bench.py times) is tested the
+same way, plus a window deep inside the clip with the oracle continuing from
+the device's exported model; configs[0] needs a video file and cv2.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -102,6 +105,83 @@ def test_config_B_720p30_5ball():
     assert total > 100 and found >= 0.97 * total
     assert abs(res.g_px_per_frame_sq / g - 1.0) < 0.02
     assert abs(res.camera_tilt) < 0.01
+
+
+# ---------------------------------------------------------------------------
+# C: 1920x1080, 60 fps, 9 balls, noisy drifting background, 1800 frames --
+# the workload bench.py's headline number is measured on
+# ---------------------------------------------------------------------------
+
+# bench.py's own report for this clip (its renderer is deterministic)
+CONFIG_C_EVENTS, CONFIG_C_ARCS = 49861, 174
+
+
+def test_config_C_1080p60_9ball_noisy():
+    from hawkeye_amd.batch import ClipScanner
+    from hawkeye_amd.detect import EventDetector, hawkeye_blob_params
+    from oracle import detect_ref as D
+    spec = synth.CLIPS['C_1080p60_9ball_noisy']
+    w, h = spec['width'], spec['height']
+    clip = synth.ClipRenderer(spec).render(0, spec['frames'])
+    torch.cuda.synchronize()
+    sc = ClipScanner(w, h, spec['fps'])
+    res = sc.scan(clip)
+    assert len(res.events) == spec['frames'] == 1800
+
+    # step 2 against the oracle, bit for bit: frames 0-255 (the alpha ramp of
+    # the first 200 frames and the first chunk borders; the oracle threaded
+    # over rows and frames gives the single-thread events, see
+    # tests/test_oracle_detect.py) ...
+    bp = D.hawkeye_params(h)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    want = D.detect_clip(clip[:256].cpu().numpy(), bp, threads=threads)
+    same_keypoints(res.events[:256], want)
+    assert sum(len(k) for k in want) > 5000
+
+    # ... and a window past frame 1000, where most tiles have left the
+    # kernel's unit path: a detector run up to frame 1024 hands its model to
+    # the oracle, which continues for 32 frames
+    det = EventDetector(w, h, hawkeye_blob_params(h), chunk=128)
+    head = []
+    for s in range(0, 1024, 128):
+        head += det.submit(clip[s:s + 128])
+    head += det.flush()
+    same_keypoints(head, res.events[:1024])     # chunks of 128 = chunks of 120
+    model = det.mog.export_model()
+    tail = det.submit(clip[1024:1056]) + det.flush()
+    model_after = det.mog.export_model()
+    det.close()
+    ref = D.Mog(w, h)
+    ref.set_state(model, 1024)
+    want = [D.blob_detect(ref.apply(f), bp)
+            for f in clip[1024:1056].cpu().numpy()]
+    same_keypoints(tail, want)
+    same_keypoints(res.events[1024:1056], want)
+    assert sum(len(k) for k in want) > 500
+    assert np.array_equal(model_after.view(np.uint32),
+                          ref.model().view(np.uint32))
+    # how far from trivial the model is there: pixels with >= 3 components
+    deep = float((model_after[:, 2, 1] > 0).mean())
+    print('config C: {:.1%} of the pixels hold three or more mixture '
+          'components after 1056 frames'.format(deep))
+    assert deep > 0.01
+
+    # the whole clip: the pipelined batch gives the same result, the numbers
+    # are the ones bench.py reports, the arcs are the rendered flights
+    again = list(sc.scan_many([clip, clip, clip]))
+    sc.close()
+    for other in again:
+        same_keypoints(other.events, res.events)
+        assert np.array_equal(other.arc_params, res.arc_params)
+        assert np.array_equal(other.final_arc, res.final_arc)
+    events = sum(len(k) for k in res.events)
+    found, total, g = flights_recovered(spec, res, tol_px=5.0)
+    print('config C: {} events, {} arcs, {}/{} flights recovered'.format(
+        events, len(res.arc_params), found, total))
+    assert events == CONFIG_C_EVENTS
+    assert len(res.arc_params) == CONFIG_C_ARCS
+    assert total > 100 and found >= 0.95 * total
+    assert abs(res.g_px_per_frame_sq / g - 1.0) < 0.02
 
 
 # ---------------------------------------------------------------------------

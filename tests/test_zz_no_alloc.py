@@ -64,15 +64,28 @@ def handle_batches(frames, splits, w, h):
     return masks, model
 
 
+def oracle_batches(host_frames, w, h):
+    from oracle import detect_ref as D
+    ref = D.Mog(w, h)
+    masks = np.stack([ref.apply(f) for f in host_frames])
+    return masks, ref.model()
+
+
 def compare(seed, t, h, w, splits):
     rng = np.random.RandomState(seed)
-    frames = torch.from_numpy(frames_moving(rng, t, h, w)).cuda()
+    host = frames_moving(rng, t, h, w)
+    frames = torch.from_numpy(host).cuda()
     want_masks, want_model = handle_batches(frames, splits, w, h)
     got_masks, got_model = static_batches(frames, splits, w, h)
     assert 0 < (want_masks == 255).mean() < 0.9
     assert np.array_equal(got_masks, want_masks)
     assert np.array_equal(got_model.view(np.uint32),
                           want_model.view(np.uint32))
+    # and against the C oracle itself, so that this file stands alone
+    ref_masks, ref_model = oracle_batches(host, w, h)
+    assert np.array_equal(got_masks, ref_masks)
+    assert np.array_equal(got_model.view(np.uint32),
+                          ref_model.view(np.uint32))
 
 
 def test_static_scratch_entry_point_equals_the_allocating_one():
