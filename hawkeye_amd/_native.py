@@ -46,7 +46,14 @@ c_void_pp = C.POINTER(C.c_void_p)
 
 
 def _sig(name, argtypes, restype=C.c_int):
-    fn = getattr(lib, name)
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        raise ImportError(
+            '{} does not export {}(): it is not a build of this tree\'s '
+            'include/hk.h{}; rebuild it (`make -C hawkeye_amd/csrc`)'.format(
+                LIB_PATH, name, ' (HK_NATIVE_LIB is set)'
+                if os.environ.get('HK_NATIVE_LIB') else '')) from None
     fn.argtypes = argtypes
     fn.restype = restype
     return fn
@@ -58,6 +65,7 @@ _sig('hk_device_count', [])
 _sig('hk_release_cached_memory', [])
 _sig('hk_set_host_threads', [C.c_int])
 _sig('hk_step3_help', [C.c_int])
+_sig('hk_step3_device_built', [])
 _sig('hk_set_self_check', [C.c_int])
 
 _sig('hk_mog_create', [C.c_int, C.c_int, C.c_int, c_void_pp])

@@ -252,8 +252,12 @@ class ClipScanner:
             # leave the detector empty, and let the clips that were complete
             # but for their last chunks reach the caller before the error
             try:
-                if open_clips:
-                    open_clips.pop()            # the clip that failed
+                # the clip that failed, if the error came from one: a clip
+                # whose chunks were all submitted is complete (the error then
+                # came from the caller's iterator or from a later clip) and
+                # is drained like the ones before it
+                if open_clips and not open_clips[-1]['closed']:
+                    open_clips.pop()
                 with torch.cuda.stream(detect_stream):
                     det.flush()
                 drain()

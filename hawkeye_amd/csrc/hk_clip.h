@@ -34,6 +34,10 @@ struct DeviceState {
     double *total = nullptr;            // [n] per-tag weight sums
     char *h_tags = nullptr;             // pinned, tag_cap * 36 bytes: the
                                         // tag arrays on their way up
+    void *uploaded = nullptr;           // hipEvent_t behind the uploads from
+                                        // h_tags; waited for before the
+                                        // workspace changes hands
+    bool upload_pending = false;
     // per-launch arc tables (grown on demand)
     int arc_cap = 0;
     double *arc_params = nullptr;       // [arc_cap][8]

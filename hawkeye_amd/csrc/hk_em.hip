@@ -460,8 +460,23 @@ constexpr size_t POOL_MAX = 48;
 std::mutex g_pool_mutex;
 std::vector<DeviceState> g_pool;
 
+// The tag uploads of em_prepare() are asynchronous copies out of the
+// workspace's pinned block.  A clip without arcs never synchronises its
+// stream (every EM call returns early), and an error path may skip the wait
+// too: before the workspace is parked, freed or its block refilled, the copies
+// must have left it -- otherwise the next owner, on another stream, could
+// overwrite h_tags under them or see its own uploads overtaken by them.
+void wait_for_uploads(DeviceState &d) {
+    if (!d.upload_pending || !d.uploaded) return;
+    DeviceGuard guard(d.device);
+    (void)hipEventSynchronize((hipEvent_t)d.uploaded);
+    d.upload_pending = false;
+}
+
 void free_workspace(DeviceState &d) {
     DeviceGuard guard(d.device);
+    wait_for_uploads(d);
+    if (d.uploaded) (void)hipEventDestroy((hipEvent_t)d.uploaded);
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
     (void)hipHostFree(d.h_tags);
@@ -517,12 +532,19 @@ int em_prepare(hk_clip &c, hipStream_t s) {
     const int rc = ensure_tag_capacity(d, c.n);
     if (rc != HK_OK) return rc;
     const size_t n = (size_t)c.n;
+    wait_for_uploads(d);        // (a workspace that em_release parked has none)
     if (n) {
         // Through the workspace's pinned block: a copy from the clip's
         // pageable vectors is a synchronous call of ~0.2 ms each that holds
         // up other threads' launches (seen in a HIP API trace of a batch).
-        // The block is the workspace's own, and the workspace is not handed
-        // on before this clip's work on `s` has been waited for.
+        // The block is the workspace's own; an event behind the copies is
+        // waited for before the workspace is handed on (wait_for_uploads).
+        if (!d.uploaded) {
+            hipEvent_t ev = nullptr;
+            HK_HIP(hipEventCreateWithFlags(
+                &ev, hipEventDisableTiming | hipEventBlockingSync));
+            d.uploaded = ev;
+        }
         const size_t cap = (size_t)d.tag_cap;
         double *hx = reinterpret_cast<double *>(d.h_tags);
         double *hy = hx + cap, *hr = hy + cap, *htw = hr + cap;
@@ -540,8 +562,18 @@ int em_prepare(hk_clip &c, hipStream_t s) {
                               hipMemcpyHostToDevice, s));
         HK_HIP(hipMemcpyAsync(d.r, hr, sizeof(double) * n,
                               hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.tw, htw, sizeof(double) * n,
-                              hipMemcpyHostToDevice, s));
+        // (pending from the first copy on, so that an error half-way still
+        // waits: the event then completes at once or behind what was queued)
+        d.upload_pending = true;
+        hipError_t e = hipMemcpyAsync(d.tw, htw, sizeof(double) * n,
+                                      hipMemcpyHostToDevice, s);
+        const hipError_t e2 = hipEventRecord((hipEvent_t)d.uploaded, s);
+        if (e == hipSuccess) e = e2;
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(s);
+            d.upload_pending = false;
+            HK_HIP(e);
+        }
     }
     d.ready = true;
     return HK_OK;
@@ -553,6 +585,7 @@ void em_release(hk_clip &c) {
         !d.list_cap && !d.merge_cap)
         return;
     d.ready = false;
+    wait_for_uploads(d);
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         if (g_pool.size() < POOL_MAX) {

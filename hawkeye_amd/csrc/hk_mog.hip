@@ -854,12 +854,19 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 // One workgroup; reads cost[], writes order[], zeroes cost[].
 // ---------------------------------------------------------------------------
 constexpr int ORDER_CLASSES = 9;
+constexpr int ORDER_LDS_GROUPS = 48 * 1024;
 
 __global__ __launch_bounds__(1024) void mog_order_k(int *__restrict__ cost,
                                                     int *__restrict__ order,
                                                     int n_blocks,
                                                     int frames_of_cost) {
     __shared__ int count[ORDER_CLASSES], start[ORDER_CLASSES];
+    // Each group's class is decided ONCE (one read of cost[b]) and kept here
+    // for the placement pass: order[] is then a permutation whatever happens
+    // to cost[] meanwhile (hk_mog_apply_batch_static shares one cost[] among
+    // all callers of a GPU; a call on another stream may write it).  Groups
+    // beyond the array (frames of more than 25 M pixels) keep launch order.
+    __shared__ unsigned char cls_of[ORDER_LDS_GROUPS];
     if (threadIdx.x < ORDER_CLASSES) count[threadIdx.x] = 0;
     __syncthreads();
     auto cls = [&](int c) {
@@ -868,8 +875,13 @@ __global__ __launch_bounds__(1024) void mog_order_k(int *__restrict__ cost,
         q = q < ORDER_CLASSES - 2 ? q : ORDER_CLASSES - 2;
         return ORDER_CLASSES - 2 - q;           // 0 = slowest
     };
-    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x)
-        atomicAdd(&count[cls(cost[b])], 1);
+    const int n_sorted = n_blocks < ORDER_LDS_GROUPS ? n_blocks
+                                                     : ORDER_LDS_GROUPS;
+    for (int b = threadIdx.x; b < n_sorted; b += blockDim.x) {
+        const int k = cls(cost[b]);
+        cls_of[b] = (unsigned char)k;
+        atomicAdd(&count[k], 1);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(1024) void mog_order_k(int *__restrict__ cost,
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-        const int pos = atomicAdd(&start[cls(cost[b])], 1);
+        const int pos = b < n_sorted ? atomicAdd(&start[cls_of[b]], 1) : b;
         order[pos] = b;
         cost[b] = 0;
     }

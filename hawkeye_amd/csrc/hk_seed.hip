@@ -43,6 +43,7 @@
 // far).  seed_open() then reports "does not apply here" and hk_arcs.cpp takes
 // its host path, as it does for a clip the fixed-size device lists cannot hold.
 #ifdef HK_NO_DEVICE_SEEDS
+extern "C" int hk_step3_device_built(void) { return 0; }
 namespace hk {
 struct SeedDevice {};
 void seed_release_cached() {}
@@ -58,6 +59,7 @@ int seed_round(SeedDevice *, int, const unsigned char *, SeedRound &) {
 }
 }  // namespace hk
 #else
+extern "C" int hk_step3_device_built(void) { return 1; }
 
 namespace {
 

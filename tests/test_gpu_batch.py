@@ -233,3 +233,60 @@ def test_frames_produced_just_before_the_scan_are_waited_for():
         for x, y in zip(a.events, b.events):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
         assert np.array_equal(a.arc_params, b.arc_params)
+
+
+def test_clips_with_tags_but_no_arcs_between_normal_ones():
+    """A clip whose events form no arc (static scene plus sensor noise blobs,
+    or a handful of frames) goes through step 4 without ever waiting for its
+    EM stream: its pooled device workspace must not change hands while the
+    tag uploads are still queued (hk_em.hip, wait_for_uploads).  Many short
+    no-arc clips between normal ones, every builder thread on its own
+    stream: the normal clips' results must not move."""
+    from hawkeye_amd.batch import ClipScanner
+    normal = [render(small_spec(4400 + i, frames=120, balls=3 + i % 2))
+              for i in range(3)]
+    # a few frames of a ball clip: events (after the first frame) but far too
+    # few for an arc
+    stub = [render(small_spec(4450 + i, frames=12))[:3 + i] for i in range(4)]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
+    want_normal = [sc.scan(c) for c in normal]
+    want_stub = [sc.scan(c) for c in stub]
+    assert all(len(r.arc_params) > 0 for r in want_normal)
+    assert all(len(r.arc_params) == 0 for r in want_stub)
+    assert any(len(r.frame) > 0 for r in want_stub)
+    order, want = [], []
+    for rep in range(6):
+        for i in range(3):
+            order += [normal[i], stub[(rep + i) % 4], stub[(rep + i + 1) % 4]]
+            want += [want_normal[i], want_stub[(rep + i) % 4],
+                     want_stub[(rep + i + 1) % 4]]
+    got = list(sc.scan_many(iter(order), count=len(order)))
+    assert len(got) == len(want)
+    for a, b in zip(want, got):
+        same_result(a, b)
+    sc.close()
+
+
+def test_an_error_of_the_clip_iterator_loses_no_finished_clip():
+    """The caller's iterator raises after two clips: both were submitted in
+    full, so both results reach the caller before the error does."""
+    from hawkeye_amd.batch import ClipScanner
+    clips = [render(small_spec(4500 + i, frames=70)) for i in range(2)]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, 30.0, device=0, chunk=32)
+    want = [sc.scan(c) for c in clips]
+
+    def source():
+        yield clips[0]
+        yield clips[1]
+        raise KeyError('no more video')
+
+    got = []
+    with pytest.raises(KeyError):
+        for res in sc.scan_many(source()):
+            got.append(res)
+    assert len(got) == 2
+    for a, b in zip(want, got):
+        same_result(a, b)
+    sc.close()

@@ -30,6 +30,9 @@ def tags_with_distractors(width, height, fps, balls, frames, seed, clutter,
 def build(monkeypatch, geometry, soa, device, window=None, self_check=False):
     from hawkeye_amd import _native as nat
     from hawkeye_amd.arcs import Clip
+    if device and not nat.lib.hk_step3_device_built():
+        pytest.skip('library built without the opt-in device side of step 3 '
+                    '(make -C hawkeye_amd/csrc DEVICE_SEEDS=1)')
     width, height, fps, frames = geometry
     frame, x, y, r, tw, start = soa
     monkeypatch.setenv('HK_STEP3_DEVICE', '2' if device else '0')
