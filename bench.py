@@ -105,7 +105,7 @@ def launch_ranks(n, argv):
 
 WORKLOAD = 'C_1080p60_9ball_noisy'
 SEGMENT_WORKLOAD = 'D_4k240_9ball_long'
-CHUNK = int(os.environ.get('HK_BENCH_CHUNK', '128'))
+CHUNK = int(os.environ.get('HK_BENCH_CHUNK', '360'))
 ALGO_BYTES_PER_PIXEL_FRAME = 324       # 3 in + 1 out + 160 model rd + 160 wr
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024                           # 256 CUs x 4

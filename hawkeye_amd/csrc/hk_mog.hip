@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -482,6 +483,12 @@ __device__ __forceinline__ void write_lane_x4(unsigned &a0, unsigned &a1,
 // ---------------------------------------------------------------------------
 // tools/probe build only (-DHK_MOG_PATH_STATS): how many wave-frames take
 // which update path (tools/probe/mog_paths.py)
+// tools/probe build only (-DHK_MOG_WAVE_TIMES): every wave of the batch
+// kernel notes when it started and ended (s_memrealtime, 100 MHz) and how
+// many of its frames left the fast step (tools/probe/mog_timeline.py)
+#ifdef HK_MOG_WAVE_TIMES
+__device__ unsigned long long *hk_mog_wave_times_dev;
+#endif
 #ifdef HK_MOG_PATH_STATS
 __device__ unsigned long long hk_mog_path_stats_dev[8];
 #define HK_PATH_STAT(i)                                                      \
@@ -511,6 +518,11 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
     // of a group take indices 8 apart and meet in one XCD's L2.  `order`
     // (may be null) lists the groups, slowest of the previous launch first:
     // see mog_order_k.
+#ifdef HK_MOG_WAVE_TIMES
+    unsigned long long wave_t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(wave_t0)::"memory");
+#endif
     const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const unsigned pos = (j >> 2) * 8 + xcd;
     if (pos >= (unsigned)n_groups) return;
@@ -816,6 +828,22 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
 
     if (cost && threadIdx.x == 0 && slow_steps)
         atomicMax(&cost[group], slow_steps);
+#ifdef HK_MOG_WAVE_TIMES
+    if (hk_mog_wave_times_dev && DEPTH > 1) {
+        unsigned long long wave_t1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(wave_t1)::"memory");
+        if (threadIdx.x == 0) {
+            unsigned long long *rec =
+                hk_mog_wave_times_dev + 4 * (unsigned long long)blockIdx.x;
+            rec[0] = wave_t0;
+            rec[1] = wave_t1;
+            rec[2] = (unsigned long long)slow_steps |
+                     ((unsigned long long)(unsigned)mode << 32);
+            rec[3] = pos;
+        }
+    }
+#endif
     if (mode < 0) lazy.w = lazy.scale = f2{1.f, 1.f};
     materialise_sk0(px, lazy, vsum);
 #pragma unroll
@@ -1152,7 +1180,11 @@ static int launch_batch(const MogTarget &m, const void *bgr_dev,
                            mask_frame_stride, nframes, frames_before,         \
                            m.alpha_table, *m.c, m.n_groups, order, cost,      \
                            (unsigned *)tiles_dev, tile_words)
-        const bool tileable = m.width % 32 == 0 && m.height % 4 == 0;
+        // (HK_MOG_UNTILED: measurements only -- 128 x 1 pixel units, whose
+        // rows are whole cache lines, on a geometry that has 32 x 4 tiles)
+        static const bool force_untiled = getenv("HK_MOG_UNTILED") != nullptr;
+        const bool tileable = m.width % 32 == 0 && m.height % 4 == 0 &&
+                              !(force_untiled && !tiles_dev);
         const long tile_words = (N / 128) * 4;
         if (tiles_dev && !tileable)
             return hk::fail(HK_ERR_ARG,
@@ -1454,6 +1486,17 @@ extern "C" int hk_mog_selfcheck_math(int device, long long *mismatches_out) {
     return HK_OK;
 }
 
+
+#ifdef HK_MOG_WAVE_TIMES
+// records: [workgroups of the batch launch][4] = start, end, slow frames |
+// mode << 32, position in the launch order; null switches the recording off
+extern "C" int hk_mog_wave_times(unsigned long long *dev_records) {
+    HK_HIP(hipDeviceSynchronize());
+    HK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hk_mog_wave_times_dev), &dev_records,
+                             sizeof(dev_records)));
+    return HK_OK;
+}
+#endif
 
 #ifdef HK_MOG_PATH_STATS
 extern "C" int hk_mog_path_stats(unsigned long long *out) {

@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--chunk', type=int, default=128)
     ap.add_argument('--config', default='C_1080p60_9ball_noisy')
+    ap.add_argument('--masks', action='store_true',
+                    help='byte masks (hk_mog_apply_batch) instead of tiles')
     ap.add_argument('--no-reset', action='store_true',
                     help='the model carries on from repetition to repetition')
     args = ap.parse_args()
@@ -46,6 +48,8 @@ def main():
     mog = BackgroundSubtractorMOG(w, h)
     blob = SimpleBlobDetector(w, h, max_frames=args.chunk)
     tiles = blob.tiles_buffer()
+    masks = torch.empty((args.chunk, h, w), dtype=torch.uint8,
+                        device='cuda') if args.masks else None
     torch.cuda.synchronize()
     times = []
     for rep in range(args.reps):
@@ -55,7 +59,10 @@ def main():
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            mog.apply_batch_tiles(frames[s:s + args.chunk], tiles)
+            if args.masks:
+                mog.apply_batch(frames[s:s + args.chunk], out=masks)
+            else:
+                mog.apply_batch_tiles(frames[s:s + args.chunk], tiles)
             e1.record()
             times.append((rep, s, e0, e1))
     torch.cuda.synchronize()
