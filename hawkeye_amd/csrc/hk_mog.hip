@@ -488,6 +488,13 @@ __device__ __forceinline__ void write_lane_x4(unsigned &a0, unsigned &a1,
 // many of its frames left the fast step (tools/probe/mog_timeline.py)
 #ifdef HK_MOG_WAVE_TIMES
 __device__ unsigned long long *hk_mog_wave_times_dev;
+// 0: the frame loads are dropped by the buffer range check (they return
+// zeros: a black static scene) while every instruction stays -- what the
+// kernel costs without its frame traffic
+__device__ int hk_mog_frame_records_dev = -1;
+#define HK_MOG_FRAME_RECORDS hk_mog_frame_records_dev
+#else
+#define HK_MOG_FRAME_RECORDS (-1)
 #endif
 #ifdef HK_MOG_PATH_STATS
 __device__ unsigned long long hk_mog_path_stats_dev[8];
@@ -640,8 +647,8 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void mog_batch2_k(
         // whole group is read again (nobody looks at the result)
         if (t + DEPTH > nframes) t = nframes >= DEPTH ? nframes - DEPTH : 0;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t *>(bgr + (long)t * bgr_frame_stride), 0, -1,
-            0x00020000);
+            const_cast<uint8_t *>(bgr + (long)t * bgr_frame_stride), 0,
+            HK_MOG_FRAME_RECORDS, 0x00020000);
         // (the host launches this kernel with nframes >= DEPTH)
         if (!last_wave) {
 #pragma unroll
@@ -1494,6 +1501,15 @@ extern "C" int hk_mog_wave_times(unsigned long long *dev_records) {
     HK_HIP(hipDeviceSynchronize());
     HK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hk_mog_wave_times_dev), &dev_records,
                              sizeof(dev_records)));
+    return HK_OK;
+}
+#endif
+
+#ifdef HK_MOG_WAVE_TIMES
+extern "C" int hk_mog_frame_records(int records) {
+    HK_HIP(hipDeviceSynchronize());
+    HK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hk_mog_frame_records_dev), &records,
+                             sizeof(records)));
     return HK_OK;
 }
 #endif

@@ -32,6 +32,10 @@ def main():
     ap.add_argument('--config', default='C_1080p60_9ball_noisy')
     ap.add_argument('--masks', action='store_true',
                     help='byte masks (hk_mog_apply_batch) instead of tiles')
+    ap.add_argument('--no-frame-traffic', action='store_true',
+                    help='probe library only (HK_NATIVE_LIB=tools/probe/'
+                         'libhk_mogtimes.so): frame loads dropped by the '
+                         'buffer range check, all instructions kept')
     ap.add_argument('--no-reset', action='store_true',
                     help='the model carries on from repetition to repetition')
     args = ap.parse_args()
@@ -51,6 +55,9 @@ def main():
     masks = torch.empty((args.chunk, h, w), dtype=torch.uint8,
                         device='cuda') if args.masks else None
     torch.cuda.synchronize()
+    if args.no_frame_traffic:
+        from hawkeye_amd import _native as nat
+        nat.check(nat.lib.hk_mog_frame_records(0))
     times = []
     for rep in range(args.reps):
         if not args.no_reset or rep == 0:

@@ -307,6 +307,23 @@ __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void dma_k(
     if (m[0].x + m[1].y + m[2].x == 1234.5f) out[0] = (float)lds[lane];
 }
 
+// Where the bytes of a 12-byte-per-lane LDS-DMA load land: lane l reads
+// dwords 3l, 3l+1, 3l+2 of a table whose dword i holds i; the LDS image is
+// copied out.
+__global__ __launch_bounds__(64) void dma12_layout_k(const unsigned *table,
+                                                     unsigned *out) {
+    __shared__ __attribute__((aligned(16))) unsigned img[512];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 512; i += 64) img[i] = 0xdeadbeefu;
+    __syncthreads();
+    const unsigned lds =
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned *)img;
+    dma12(reinterpret_cast<const uint8_t *>(table), (unsigned)lane * 12u, lds);
+    wait_vm<0>();
+    __syncthreads();
+    for (int i = lane; i < 512; i += 64) out[i] = img[i];
+}
+
 // ---------------------------------------------------------------------------
 static float timed(void (*launch)(), int reps) {
     hipEvent_t e0, e1;
@@ -393,6 +410,19 @@ static int run(const std::string &which) {
                            40, g_sink);
         CHECK(hipDeviceSynchronize());
         printf("plane8r  bytes_read %ld\n", 40 * NPIX * 4);
+        return 0;
+    }
+    if (which == "dma12layout") {
+        unsigned *tab, *out, host[512];
+        CHECK(hipMalloc((void **)&tab, 4096));
+        CHECK(hipMalloc((void **)&out, 4096));
+        for (int i = 0; i < 512; ++i) host[i] = i;
+        CHECK(hipMemcpy(tab, host, 2048, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(dma12_layout_k, dim3(1), dim3(64), 0, 0, tab, out);
+        CHECK(hipMemcpy(host, out, 2048, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 256; ++i)
+            printf("%s%d", i % 16 ? " " : "\n", (int)host[i]);
+        printf("\n");
         return 0;
     }
     if (which == "plane8w") {
