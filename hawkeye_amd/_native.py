@@ -160,6 +160,7 @@ _sig('hk_clip_get_arcs', [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
 _sig('hk_clip_get_tag_state', [C.c_void_p, C.c_void_p, C.c_void_p])
 _sig('hk_clip_build_initial_arcs', [C.c_void_p])
 _sig('hk_clip_em_optimize', [C.c_void_p, C.c_void_p])
+_sig('hk_clips_em_optimize', [C.POINTER(C.c_void_p), C.c_int, C.c_void_p])
 _sig('hk_clip_calculate_weights', [C.c_void_p, C.c_void_p])
 _sig('hk_clip_fit_arcs', [C.c_void_p, C.c_void_p])
 _sig('hk_clip_estimate_camera_tilt', [C.c_void_p, C.c_void_p])

@@ -153,6 +153,25 @@ class Clip:
     def em_optimize(self):
         self._run(nat.lib.hk_clip_em_optimize(self._h, self._stream_ptr()))
 
+    @staticmethod
+    def em_optimize_many(clips, stream=None):
+        """Step 4 of several clips of one device in lockstep
+        (hk_clips_em_optimize): every EM kernel is launched once over the
+        arcs of all of them.  Each clip ends up as em_optimize() leaves it."""
+        clips = list(clips)
+        if not clips:
+            return
+        handles = (C.c_void_p * len(clips))(*[c._h for c in clips])
+        if stream is None:
+            stream = clips[0]._stream_ptr()
+        status = nat.lib.hk_clips_em_optimize(handles, len(clips), stream)
+        if status == -5:
+            for c in clips:
+                if getattr(c, '_error', None) is not None:
+                    exc, c._error = c._error, None
+                    raise exc
+        nat.check(status)
+
     def calculate_weights(self):
         self._run(nat.lib.hk_clip_calculate_weights(self._h,
                                                     self._stream_ptr()))

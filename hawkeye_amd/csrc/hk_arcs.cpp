@@ -1558,61 +1558,92 @@ void host_merge_trial(const hk_clip &c, const Arc &a1, const MergeCache &m1,
 //    pair are cached per arc and refreshed only for the arc a merger changed;
 //  * the trial fits of ALL candidate pairs of the pass are evaluated up
 //    front in one kernel launch (K8 merge_trials_k, bit-identical to the
-//    host's trial fit); the scan below then only looks results up, and
-//    computes on the host the pairs that involve an arc changed by a merger
-//    of this pass.
-int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
-    const Rot rot = rotation(c);
-    std::vector<double> dist;
-    std::vector<long> off;
-    int rc = em_member_distances(c, stream, dist, off);
-    if (rc != HK_OK) return rc;
-    const size_t A0 = c.arcs.size();
-    std::vector<MergeCache> cache(A0);
-    for (size_t k = 0; k < A0; ++k)
-        refresh_cache(c, c.arcs[k], rot, dist.data() + off[k], cache[k]);
+//    host's trial fit) -- for all clips of a batch at once, which is why the
+//    phase comes in two halves: merge_prepare() lists a clip's candidate
+//    pairs, em_merge_trials() runs those of every clip, and merge_scan() then
+//    only looks results up, computing on the host the pairs that involve an
+//    arc changed by a merger of this pass.
+struct MergeWork {
+    Rot rot{0, 1};
+    std::vector<MergeCache> cache;
+    // member distances per arc (arc.tags order): from K7 for the arcs as the
+    // pass found them, recomputed here for an arc a merger changed; what
+    // prune_phase() then reads instead of asking the device again
+    std::vector<std::vector<double>> adist;
+    MergeInput in;                  // good-tag lists (CSR) and pairs
+    std::vector<int> pair_start;    // first pair of each i1
+    bool launched = false;          // the pairs went to the device
+};
 
+void merge_prepare(hk_clip &c, const std::vector<double> &dist,
+                   const std::vector<long> &off, MergeWork &mw) {
+    mw.rot = rotation(c);
+    const size_t A0 = c.arcs.size();
+    mw.cache.assign(A0, MergeCache());
+    mw.adist.assign(A0, std::vector<double>());
+    for (size_t k = 0; k < A0; ++k) {
+        refresh_cache(c, c.arcs[k], mw.rot, dist.data() + off[k], mw.cache[k]);
+        mw.adist[k].assign(dist.begin() + off[k], dist.begin() + off[k + 1]);
+    }
+    const std::vector<MergeCache> &cache = mw.cache;
     auto candidate = [&](size_t i1, size_t i2) {    // the cheap tests
         return !(cache[i2].f_max < cache[i1].f_min ||
                  cache[i2].f_min > cache[i1].f_max) &&
                cache[i2].good.size() >= 3;
     };
-
     // every pair the scan could reach with the arcs as they are now
     // (pairs are generated by ascending i1, then ascending i2: pair_start[i1]
     // = first pair of i1, and i2 is found by bisection -- memory stays linear
     // in the number of candidate pairs however many arcs there are)
-    std::vector<int> pairs, pair_start;
-    std::vector<MergeTrial> trials;
-    const bool verify = g_self_check.load() != 0;
-    {
-        for (size_t i1 = 0; i1 < A0; ++i1) {
-            if (c.arcs[i1].done || c.arcs[i1].tags.empty() ||
-                cache[i1].good.size() < 3)
-                continue;
-            for (size_t i2 = 0; i2 < A0; ++i2)
-                if (i2 != i1 && !c.arcs[i2].tags.empty() && candidate(i1, i2)) {
-                    pairs.push_back((int)i1);
-                    pairs.push_back((int)i2);
-                }
-        }
-        if (pairs.size() / 2 >= 128) {      // else not worth a launch
-            std::vector<int> good_off(A0 + 1, 0), good;
-            for (size_t k = 0; k < A0; ++k) {
-                good.insert(good.end(), cache[k].good.begin(),
-                            cache[k].good.end());
-                good_off[k + 1] = (int)good.size();
+    std::vector<int> &pairs = mw.in.pairs;
+    pairs.clear();
+    mw.in.good_off.clear();
+    mw.in.good.clear();
+    mw.pair_start.clear();
+    mw.launched = false;
+    for (size_t i1 = 0; i1 < A0; ++i1) {
+        if (c.arcs[i1].done || c.arcs[i1].tags.empty() ||
+            cache[i1].good.size() < 3)
+            continue;
+        for (size_t i2 = 0; i2 < A0; ++i2)
+            if (i2 != i1 && !c.arcs[i2].tags.empty() && candidate(i1, i2)) {
+                pairs.push_back((int)i1);
+                pairs.push_back((int)i2);
             }
-            rc = em_merge_trials(c, stream, good_off, good, pairs, trials);
-            if (rc != HK_OK) return rc;
-            pair_start.assign(A0 + 1, 0);
-            for (size_t q = 0; q < pairs.size() / 2; ++q)
-                ++pair_start[(size_t)pairs[2 * q] + 1];
-            for (size_t k = 0; k < A0; ++k) pair_start[k + 1] += pair_start[k];
-        }
     }
+    if (pairs.size() / 2 >= 128) {      // else not worth a place in the launch
+        mw.in.good_off.assign(A0 + 1, 0);
+        for (size_t k = 0; k < A0; ++k) {
+            mw.in.good.insert(mw.in.good.end(), cache[k].good.begin(),
+                              cache[k].good.end());
+            mw.in.good_off[k + 1] = (int)mw.in.good.size();
+        }
+        mw.pair_start.assign(A0 + 1, 0);
+        for (size_t q = 0; q < pairs.size() / 2; ++q)
+            ++mw.pair_start[(size_t)pairs[2 * q] + 1];
+        for (size_t k = 0; k < A0; ++k)
+            mw.pair_start[k + 1] += mw.pair_start[k];
+        mw.launched = true;
+    } else {
+        pairs.clear();
+    }
+}
+
+int merge_scan(hk_clip &c, MergeWork &mw, const std::vector<MergeTrial> &trials,
+               bool &merged_any) {
+    const Rot rot = mw.rot;
+    std::vector<MergeCache> &cache = mw.cache;
+    const std::vector<int> &pairs = mw.in.pairs;
+    const std::vector<int> &pair_start = mw.pair_start;
+    const size_t A0 = cache.size();
+    const bool verify = g_self_check.load() != 0;
+    auto candidate = [&](size_t i1, size_t i2) {
+        return !(cache[i2].f_max < cache[i1].f_min ||
+                 cache[i2].f_min > cache[i1].f_max) &&
+               cache[i2].good.size() >= 3;
+    };
     auto find_trial = [&](size_t o1, size_t o2) -> const MergeTrial * {
-        if (pair_start.empty()) return nullptr;
+        if (!mw.launched) return nullptr;
         int lo = pair_start[o1], hi = pair_start[o1 + 1];
         while (lo < hi) {
             const int mid = (lo + hi) / 2;
@@ -1684,9 +1715,13 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
                 a1.tags = trial_tags;
                 a1.w_off = -1;
                 refresh_cache(c, a1, rot, nullptr, cache[i1]);
+                mw.adist[i1].resize(a1.tags.size());
+                for (size_t k = 0; k < a1.tags.size(); ++k)
+                    mw.adist[i1][k] = arc_tag_distance(c, a1, rot, a1.tags[k]);
                 changed[o1] = 1;
                 c.arcs.erase(c.arcs.begin() + (long)i2);
                 cache.erase(cache.begin() + (long)i2);
+                mw.adist.erase(mw.adist.begin() + (long)i2);
                 orig.erase(orig.begin() + (long)i2);
                 merged = true;
                 merged_any = true;
@@ -1694,7 +1729,7 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
             }
             if (!merged) {
                 c.arcs[i1].done = true;
-                rc = report_progress(c);
+                const int rc = report_progress(c);
                 if (rc != HK_OK) return rc;
             }
         }
@@ -1704,11 +1739,9 @@ int merge_phase(hk_clip &c, hipStream_t stream, bool &merged_any) {
 
 // All of "while self.prune_arcs(arcs): ..." (reference tracker.py:969-970,
 // 1288-1329): arcs do not change between passes, so every failing arc goes.
-int prune_phase(hk_clip &c, hipStream_t stream, bool &pruned_any) {
-    std::vector<double> dist;
-    std::vector<long> off;
-    const int rc = em_member_distances(c, stream, dist, off);
-    if (rc != HK_OK) return rc;
+// adist: the member distances of every arc as it stands (see MergeWork).
+int prune_phase(hk_clip &c, const std::vector<std::vector<double>> &adist,
+                bool &pruned_any) {
     std::vector<Arc> kept;
     kept.reserve(c.arcs.size());
     for (size_t k = 0; k < c.arcs.size(); ++k) {
@@ -1723,8 +1756,8 @@ int prune_phase(hk_clip &c, hipStream_t stream, bool &pruned_any) {
             code = 4;
         } else {
             int close = 0;
-            for (size_t j = 0; j < arc.tags.size(); ++j)
-                if (dist[off[k] + (long)j] < c.p.max_distance_pixels) ++close;
+            for (double dd : adist[k])
+                if (dd < c.p.max_distance_pixels) ++close;
             if (close < c.p.min_tags_per_arc) code = 2;
         }
         if (code == 0) {
@@ -2092,9 +2125,22 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
     return HK_OK;
 }
 
-extern "C" int hk_clip_em_optimize(hk_clip *c, void *stream) {
-    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_em_optimize: null clip");
-    const hipStream_t s = (hipStream_t)stream;
+// EM_optimize (reference tracker.py:912-990) for a batch of clips in
+// lockstep.  The reference's loop, per clip:
+//     tilt, fit, merge*, prune*, E-step, fit      while anything was merged
+//     clean_notes, tilt, fit, sort                or pruned
+// Every device phase is one launch over the arcs of all clips that are at
+// that point of their loop, and one stream synchronisation, however many
+// clips that is; the order-dependent decisions (merge scan, prune, clean) stay
+// per clip on the host, exactly as for a clip on its own, so the results do
+// not depend on what a clip shares its batch with.  Phases whose inputs are
+// already on the device follow each other without a host round trip (the
+// M-step behind the E-step), and prune reads the distances the merge phase
+// fetched.
+// own: the batch to work in (a clip's own batch of one, which may hold E-step
+// weights from hk_clip_calculate_weights), or null to open one for the call.
+static int em_optimize_batch(hk_clip *const *clips, int n, hipStream_t s,
+                             hk::EmBatch *own = nullptr) {
     const bool stats = getenv("HK_STEP4_STATS") != nullptr;
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rounds = 0;
@@ -2106,51 +2152,138 @@ extern "C" int hk_clip_em_optimize(hk_clip *c, void *stream) {
                         std::chrono::steady_clock::now() - t0).count();
         return r;
     };
-    int rc = timed(0, HK_OK, [&] { return hk::em_prepare(*c, s); });
-    bool again = true;
-    while (again && rc == HK_OK) {
-        ++rounds;
-        rc = timed(1, rc, [&] { return hk::em_tilt(*c, s); });
-        rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
-        again = false;
-        for (Arc &a : c->arcs) a.done = false;
-        rc = timed(3, rc, [&] { return hk::merge_phase(*c, s, again); });
-        rc = timed(4, rc, [&] { return hk::prune_phase(*c, s, again); });
-        rc = timed(5, rc, [&] { return hk::em_estep(*c, s); });
-        rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
-    }
-    rc = timed(6, rc, [&] { return hk::clean(*c); });
-    rc = timed(1, rc, [&] { return hk::em_tilt(*c, s); });
-    rc = timed(2, rc, [&] { return hk::em_fit(*c, s); });
+    hk::EmBatch *b = own;
+    int rc = HK_OK;
+    if (!b) rc = timed(0, HK_OK, [&] { return hk::em_open(clips, n, s, &b); });
     if (rc != HK_OK) return rc;
-    hk::sort_arcs_by_peak(*c);
+    std::vector<int> act((size_t)n), finishing;
+    std::iota(act.begin(), act.end(), 0);
+    std::vector<hk::MergeWork> work((size_t)n);
+    std::vector<std::vector<double>> dist;
+    std::vector<std::vector<long>> off;
+    std::vector<hk::MergeInput> inputs;
+    std::vector<std::vector<hk::MergeTrial>> trials;
+    // act: clips at the top of their loop; finishing: clips that have left it
+    // and been cleaned, with the last tilt + fit to come -- which they share
+    // with the next round of the others
+    while (rc == HK_OK && (!act.empty() || !finishing.empty())) {
+        ++rounds;
+        std::vector<int> both(act);
+        both.insert(both.end(), finishing.begin(), finishing.end());
+        rc = timed(1, rc, [&] { return hk::em_tilt(*b, both); });
+        rc = timed(2, rc, [&] { return hk::em_fit(*b, both); });
+        finishing.clear();
+        if (act.empty() || rc != HK_OK) break;
+
+        std::vector<char> again(act.size(), 0);
+        for (int ci : act)
+            for (Arc &a : clips[ci]->arcs) a.done = false;
+        rc = timed(3, rc, [&] {
+            int r = hk::em_member_distances(*b, act, dist, off);
+            if (r != HK_OK) return r;
+            inputs.assign(act.size(), hk::MergeInput());
+            for (size_t j = 0; j < act.size(); ++j) {
+                hk::MergeWork &mw = work[(size_t)act[j]];
+                hk::merge_prepare(*clips[act[j]], dist[j], off[j], mw);
+                inputs[j] = mw.in;
+            }
+            r = hk::em_merge_trials(*b, act, inputs, trials);
+            for (size_t j = 0; j < act.size() && r == HK_OK; ++j) {
+                bool merged = false;
+                r = hk::merge_scan(*clips[act[j]], work[(size_t)act[j]],
+                                   trials[j], merged);
+                again[j] = again[j] || merged;
+            }
+            return r;
+        });
+        rc = timed(4, rc, [&] {
+            int r = HK_OK;
+            for (size_t j = 0; j < act.size() && r == HK_OK; ++j) {
+                bool pruned = false;
+                r = hk::prune_phase(*clips[act[j]],
+                                    work[(size_t)act[j]].adist, pruned);
+                again[j] = again[j] || pruned;
+            }
+            return r;
+        });
+        rc = timed(5, rc, [&] { return hk::em_estep(*b, act, true); });
+        std::vector<int> next;
+        for (size_t j = 0; j < act.size() && rc == HK_OK; ++j) {
+            if (again[j]) {
+                next.push_back(act[j]);
+            } else {
+                rc = timed(6, rc, [&] { return hk::clean(*clips[act[j]]); });
+                finishing.push_back(act[j]);
+            }
+        }
+        act.swap(next);
+    }
+    if (!own) hk::em_close(b);
+    if (rc != HK_OK) return rc;
+    for (int k = 0; k < n; ++k) hk::sort_arcs_by_peak(*clips[k]);
     if (stats)
         fprintf(stderr,
-                "step4: %d rounds; prepare %.2f, tilt %.2f, fit %.2f, merge "
-                "%.2f, prune %.2f, E-step %.2f, clean %.2f ms\n",
-                rounds, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);
+                "step4: %d clips, %d rounds; open %.2f, tilt %.2f, fit %.2f, "
+                "merge %.2f, prune %.2f, E+M step %.2f, clean %.2f ms\n",
+                n, rounds, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);
     return HK_OK;
 }
 
+extern "C" int hk_clip_em_optimize(hk_clip *c, void *stream) {
+    if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_em_optimize: null clip");
+    // (a clip that ran single operations carries on in its own batch, where
+    // its E-step weights are)
+    if (c->own) c->own->stream = (hipStream_t)stream;
+    return em_optimize_batch(&c, 1, (hipStream_t)stream, c->own);
+}
+
+extern "C" int hk_clips_em_optimize(hk_clip *const *clips, int nclips,
+                                    void *stream) {
+    if (nclips < 0 || (nclips > 0 && !clips))
+        return hk::fail(HK_ERR_ARG, "hk_clips_em_optimize: bad argument");
+    for (int k = 0; k < nclips; ++k) {
+        if (!clips[k])
+            return hk::fail(HK_ERR_ARG, "hk_clips_em_optimize: clip %d is null",
+                            k);
+        for (int j = 0; j < k; ++j)
+            if (clips[j] == clips[k])
+                return hk::fail(HK_ERR_ARG,
+                                "hk_clips_em_optimize: clip %d listed twice",
+                                k);
+    }
+    if (nclips == 0) return HK_OK;
+    for (int k = 0; k < nclips; ++k)
+        if (clips[k]->own)
+            return hk::fail(HK_ERR_ARG,
+                            "hk_clips_em_optimize: clip %d has run single EM "
+                            "operations (its weights live in a batch of its "
+                            "own); use hk_clip_em_optimize for it", k);
+    return em_optimize_batch(clips, nclips, (hipStream_t)stream);
+}
+
+// The single operations work in the clip's own batch of one.
 extern "C" int hk_clip_calculate_weights(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_calculate_weights: null");
-    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
+    hk::EmBatch *b = nullptr;
+    const int rc = hk::em_own(*c, (hipStream_t)stream, &b);
     if (rc != HK_OK) return rc;
-    return hk::em_estep(*c, (hipStream_t)stream);
+    return hk::em_estep(*b, {0}, false);
 }
 
 extern "C" int hk_clip_fit_arcs(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_fit_arcs: null clip");
-    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
+    hk::EmBatch *b = nullptr;
+    const int rc = hk::em_own(*c, (hipStream_t)stream, &b);
     if (rc != HK_OK) return rc;
-    return hk::em_fit(*c, (hipStream_t)stream);
+    return hk::em_fit(*b, {0});
 }
 
 extern "C" int hk_clip_estimate_camera_tilt(hk_clip *c, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_estimate_camera_tilt: null");
-    const int rc = hk::em_prepare(*c, (hipStream_t)stream);
+    hk::EmBatch *b = nullptr;
+    const int rc = hk::em_own(*c, (hipStream_t)stream, &b);
     if (rc != HK_OK) return rc;
-    return hk::em_tilt(*c, (hipStream_t)stream);
+    return hk::em_tilt(*b, {0});
 }
 
 extern "C" int hk_clip_eval_arc(hk_clip *c, int index, int requirepeak,
@@ -2165,13 +2298,14 @@ extern "C" int hk_clip_member_distances(hk_clip *c, double *dist,
                                         void *stream) {
     if (!c || !dist)
         return hk::fail(HK_ERR_ARG, "hk_clip_member_distances: null");
-    int rc = hk::em_prepare(*c, (hipStream_t)stream);
+    hk::EmBatch *b = nullptr;
+    int rc = hk::em_own(*c, (hipStream_t)stream, &b);
     if (rc != HK_OK) return rc;
-    std::vector<double> d;
-    std::vector<long> off;
-    rc = hk::em_member_distances(*c, (hipStream_t)stream, d, off);
+    std::vector<std::vector<double>> d;
+    std::vector<std::vector<long>> off;
+    rc = hk::em_member_distances(*b, {0}, d, off);
     if (rc != HK_OK) return rc;
-    std::copy(d.begin(), d.end(), dist);
+    std::copy(d[0].begin(), d[0].end(), dist);
     return HK_OK;
 }
 

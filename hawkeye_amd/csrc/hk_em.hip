@@ -52,9 +52,11 @@ __device__ __forceinline__ void position(const double *__restrict__ p,
 
 __global__ __launch_bounds__(256) void estep_raw_k(
     const TagArrays tg, const double *__restrict__ arc_params,
-    const long *__restrict__ arc_win, double *__restrict__ weights, double sn,
-    double cs, double sigmasq) {
+    const long *__restrict__ arc_win, double *__restrict__ weights,
+    const int *__restrict__ arc_clip, const hk::ClipDev *__restrict__ clip) {
     const int a = blockIdx.x;
+    const double sn = clip[arc_clip[a]].sn, cs = clip[arc_clip[a]].cs;
+    const double sigmasq = clip[arc_clip[a]].sigmasq;
     const double *p = arc_params + (long)a * AP;
     const long lo = arc_win[a * AW], hi = arc_win[a * AW + 1];
     const long off = arc_win[a * AW + 2];
@@ -73,11 +75,16 @@ __global__ __launch_bounds__(256) void estep_raw_k(
     }
 }
 
+// grid: (blocks of 256 tags, clips of the launch)
 __global__ __launch_bounds__(256) void estep_total_k(
-    int n, int narcs, const long *__restrict__ arc_win,
+    const hk::ClipDev *__restrict__ clip, const long *__restrict__ arc_win_all,
     const double *__restrict__ weights, double *__restrict__ total) {
     __shared__ long win[256 * 3];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const hk::ClipDev cd = clip[blockIdx.y];
+    if ((int)(blockIdx.x * 256) >= cd.n_tags) return;   // the whole workgroup
+    const int n = cd.tag_base + cd.n_tags, narcs = cd.n_arcs;
+    const long *arc_win = arc_win_all + (long)cd.arc_base * AW;
+    const int i = cd.tag_base + blockIdx.x * 256 + threadIdx.x;
     double sum = 0.0;
     for (int base = 0; base < narcs; base += 256) {
         const int m = min(256, narcs - base);
@@ -140,10 +147,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(64) void arc_moments_k(
     const TagArrays tg, const double *__restrict__ arc_params,
     const long *__restrict__ arc_win, const double *__restrict__ weights,
-    const int *__restrict__ list, double *__restrict__ arc_out, double sn,
-    double cs, int what) {
+    const int *__restrict__ list, double *__restrict__ arc_out,
+    const int *__restrict__ arc_clip, const hk::ClipDev *__restrict__ clip,
+    int what) {
     const int a = blockIdx.x;
     const int lane = threadIdx.x;
+    const double sn = clip[arc_clip[a]].sn, cs = clip[arc_clip[a]].cs;
     const double *p = arc_params + (long)a * AP;
     const long lo = arc_win[a * AW], hi = arc_win[a * AW + 1];
     const long off = arc_win[a * AW + 2];
@@ -236,8 +245,10 @@ __global__ __launch_bounds__(64) void arc_moments_k(
 __global__ __launch_bounds__(64) void member_dist_k(
     const TagArrays tg, const double *__restrict__ arc_params,
     const long *__restrict__ arc_win, const int *__restrict__ list,
-    double *__restrict__ list_out, double sn, double cs) {
+    double *__restrict__ list_out, const int *__restrict__ arc_clip,
+    const hk::ClipDev *__restrict__ clip) {
     const int a = blockIdx.x;
+    const double sn = clip[arc_clip[a]].sn, cs = clip[arc_clip[a]].cs;
     const double *p = arc_params + (long)a * AP;
     const long lo = arc_win[a * AW], hi = arc_win[a * AW + 1];
     for (long s = lo + threadIdx.x; s < hi; s += 64) {
@@ -256,14 +267,19 @@ __global__ __launch_bounds__(64) void member_dist_k(
 // bit -- fits the trial parabola and counts the tags it leaves farther than
 // max_distance_pixels (up to 3).  Latency-bound: ~10^3-10^4 pairs of ~10^2
 // tags; what it buys is all trial fits of a merge pass in one launch.
+// (arcs, good-tag lists and pairs of all clips of the launch end to end:
+// pairs hold rows of params5 / good_off, the lists tags of the batch)
 __global__ __launch_bounds__(64) void merge_trials_k(
     TagArrays tg, const double *__restrict__ params5,
     const int *__restrict__ good_off, const int *__restrict__ good,
     const int *__restrict__ pairs, int npairs, hk::MergeTrial *__restrict__ out,
-    double sn, double cs, double maxd, int min_tags) {
+    const int *__restrict__ arc_clip, const hk::ClipDev *__restrict__ clip) {
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= npairs) return;
     const int i1 = pairs[2 * q], i2 = pairs[2 * q + 1];
+    const hk::ClipDev cd = clip[arc_clip[i1]];
+    const double sn = cd.sn, cs = cd.cs, maxd = cd.maxd;
+    const int min_tags = cd.min_tags;
     const int lo1 = good_off[i1], hi1 = good_off[i1 + 1];
     const int lo2 = good_off[i2], hi2 = good_off[i2 + 1];
     hk::MergeTrial r;
@@ -322,19 +338,37 @@ int ensure_arc_capacity(hk::DeviceState &d, int narcs) {
     if (narcs <= d.arc_cap) return HK_OK;
     const int cap = std::max(256, narcs * 2);
     (void)hipFree(d.arc_params); (void)hipFree(d.arc_win);
-    (void)hipFree(d.arc_out);
+    (void)hipFree(d.arc_out); (void)hipFree(d.arc_clip);
     (void)hipHostFree(d.h_arc_params); (void)hipHostFree(d.h_arc_win);
-    (void)hipHostFree(d.h_arc_out);
+    (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_arc_clip);
     d.arc_params = nullptr; d.arc_win = nullptr; d.arc_out = nullptr;
+    d.arc_clip = nullptr;
     d.h_arc_params = nullptr; d.h_arc_win = nullptr; d.h_arc_out = nullptr;
+    d.h_arc_clip = nullptr;
     d.arc_cap = 0;
     HK_HIP(dev_alloc(d.arc_params, (size_t)cap * AP));
     HK_HIP(dev_alloc(d.arc_win, (size_t)cap * AW));
     HK_HIP(dev_alloc(d.arc_out, (size_t)cap * AP));
+    HK_HIP(dev_alloc(d.arc_clip, (size_t)cap));
     HK_HIP(pin_alloc(d.h_arc_params, (size_t)cap * AP));
     HK_HIP(pin_alloc(d.h_arc_win, (size_t)cap * AW));
     HK_HIP(pin_alloc(d.h_arc_out, (size_t)cap * AP));
+    HK_HIP(pin_alloc(d.h_arc_clip, (size_t)cap));
     d.arc_cap = cap;
+    return HK_OK;
+}
+
+int ensure_clip_capacity(hk::DeviceState &d, int nclips) {
+    if (nclips <= d.clip_cap) return HK_OK;
+    const int cap = std::max(16, nclips * 2);
+    (void)hipFree(d.clip_tab);
+    (void)hipHostFree(d.h_clip_tab);
+    d.clip_tab = nullptr;
+    d.h_clip_tab = nullptr;
+    d.clip_cap = 0;
+    HK_HIP(dev_alloc(d.clip_tab, (size_t)cap));
+    HK_HIP(pin_alloc(d.h_clip_tab, (size_t)cap));
+    d.clip_cap = cap;
     return HK_OK;
 }
 
@@ -377,41 +411,90 @@ int ensure_list_capacity(hk::DeviceState &d, long entries) {
     return HK_OK;
 }
 
+// The clip table and the row ranges of a launch over the clips `act`: clip
+// act[j] takes rows [b.arc_base[j], b.arc_base[j] + arcs of that clip).
+int stage_clips(hk::EmBatch &b, const std::vector<int> &act) {
+    hk::DeviceState &d = b.dev;
+    int rc = ensure_clip_capacity(d, (int)act.size());
+    if (rc != HK_OK) return rc;
+    b.arc_base.assign(act.size(), 0);
+    int rows = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const hk_clip &c = *b.clips[(size_t)act[j]];
+        const hk::Rot rot = hk::rotation(c);
+        hk::ClipDev &cd = d.h_clip_tab[j];
+        cd.sn = rot.s;
+        cd.cs = rot.c;
+        cd.sigmasq = c.p.sigmasq;
+        cd.maxd = c.p.max_distance_pixels;
+        cd.tag_base = b.tag_base[(size_t)act[j]];
+        cd.n_tags = c.n;
+        cd.arc_base = rows;
+        cd.n_arcs = (int)c.arcs.size();
+        cd.min_tags = c.p.min_tags_per_arc;
+        cd.pad = 0;
+        b.arc_base[j] = rows;
+        rows += cd.n_arcs;
+    }
+    b.rows = rows;
+    rc = ensure_arc_capacity(d, rows);
+    if (rc != HK_OK) return rc;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const int n = d.h_clip_tab[j].n_arcs;
+        std::fill(d.h_arc_clip + b.arc_base[j], d.h_arc_clip + b.arc_base[j] + n,
+                  (int)j);
+    }
+    return HK_OK;
+}
+
 // Fills the pinned arc tables.  Arcs with dense weights keep their window;
-// the others get their explicit member list appended to h_list.
-int stage_arcs(hk_clip &c, long &list_entries) {
-    hk::DeviceState &d = c.dev;
-    const int A = (int)c.arcs.size();
-    int rc = ensure_arc_capacity(d, A);
+// the others get their explicit member list appended to h_list.  Tags are
+// numbered within the batch.
+int stage_arcs(hk::EmBatch &b, const std::vector<int> &act,
+               long &list_entries) {
+    hk::DeviceState &d = b.dev;
+    int rc = stage_clips(b, act);
     if (rc != HK_OK) return rc;
     long total = 0;
-    for (const hk::Arc &arc : c.arcs)
-        if (arc.w_off < 0) total += (long)arc.tags.size();
+    for (int ci : act)
+        for (const hk::Arc &arc : b.clips[(size_t)ci]->arcs)
+            if (arc.w_off < 0) total += (long)arc.tags.size();
     rc = ensure_list_capacity(d, total);
     if (rc != HK_OK) return rc;
     long pos = 0;
-    for (int k = 0; k < A; ++k) {
-        const hk::Arc &arc = c.arcs[k];
-        double *p = d.h_arc_params + (long)k * AP;
-        p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
-        p[4] = arc.f_peak; p[5] = p[6] = p[7] = 0.0;
-        long *w = d.h_arc_win + (long)k * AW;
-        if (arc.w_off >= 0) {
-            w[0] = arc.w_lo; w[1] = arc.w_hi; w[2] = arc.w_off; w[3] = 0;
-        } else {
-            w[0] = pos;
-            for (int i : arc.tags) d.h_list[pos++] = i;
-            w[1] = pos; w[2] = -1; w[3] = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const hk_clip &c = *b.clips[(size_t)act[j]];
+        const int base = b.tag_base[(size_t)act[j]];
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            const hk::Arc &arc = c.arcs[k];
+            const long row = b.arc_base[j] + (long)k;
+            double *p = d.h_arc_params + row * AP;
+            p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
+            p[4] = arc.f_peak; p[5] = p[6] = p[7] = 0.0;
+            long *w = d.h_arc_win + row * AW;
+            if (arc.w_off >= 0) {
+                w[0] = base + arc.w_lo; w[1] = base + arc.w_hi;
+                w[2] = arc.w_off; w[3] = 0;
+            } else {
+                w[0] = pos;
+                for (int i : arc.tags) d.h_list[pos++] = base + i;
+                w[1] = pos; w[2] = -1; w[3] = 0;
+            }
         }
     }
     list_entries = pos;
     return HK_OK;
 }
 
-int upload_arcs(hk_clip &c, long list_entries, hipStream_t s) {
-    hk::DeviceState &d = c.dev;
-    const size_t A = c.arcs.size();
+int upload_arcs(hk::EmBatch &b, size_t nclips, long list_entries) {
+    hk::DeviceState &d = b.dev;
+    const hipStream_t s = b.stream;
+    const size_t A = (size_t)b.rows;
     if (A == 0) return HK_OK;
+    HK_HIP(hipMemcpyAsync(d.clip_tab, d.h_clip_tab, sizeof(hk::ClipDev) * nclips,
+                          hipMemcpyHostToDevice, s));
+    HK_HIP(hipMemcpyAsync(d.arc_clip, d.h_arc_clip, sizeof(int) * A,
+                          hipMemcpyHostToDevice, s));
     HK_HIP(hipMemcpyAsync(d.arc_params, d.h_arc_params, sizeof(double) * A * AP,
                           hipMemcpyHostToDevice, s));
     HK_HIP(hipMemcpyAsync(d.arc_win, d.h_arc_win, sizeof(long) * A * AW,
@@ -422,50 +505,66 @@ int upload_arcs(hk_clip &c, long list_entries, hipStream_t s) {
     return HK_OK;
 }
 
-int run_moments(hk_clip &c, hipStream_t s, int what) {
-    hk::DeviceState &d = c.dev;
-    const int A = (int)c.arcs.size();
-    if (A == 0) return HK_OK;
-    long entries = 0;
-    int rc = stage_arcs(c, entries);
-    if (rc != HK_OK) return rc;
-    rc = upload_arcs(c, entries, s);
-    if (rc != HK_OK) return rc;
-    const hk::Rot rot = hk::rotation(c);
-    hipLaunchKernelGGL(arc_moments_k, dim3(A), dim3(64), 0, s, tag_arrays(d),
-                       d.arc_params, d.arc_win, d.weights, d.list, d.arc_out,
-                       rot.s, rot.c, what);
+int launch_moments(hk::EmBatch &b, int what) {
+    hk::DeviceState &d = b.dev;
+    hipLaunchKernelGGL(arc_moments_k, dim3((unsigned)b.rows), dim3(64), 0,
+                       b.stream, tag_arrays(d), d.arc_params, d.arc_win,
+                       d.weights, d.list, d.arc_out, d.arc_clip, d.clip_tab,
+                       what);
     HK_LAUNCH_CHECK("arc_moments_k");
-    HK_HIP(hipMemcpyAsync(d.h_arc_out, d.arc_out, sizeof(double) * A * AP,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipStreamSynchronize(s));
+    HK_HIP(hipMemcpyAsync(d.h_arc_out, d.arc_out,
+                          sizeof(double) * (size_t)b.rows * AP,
+                          hipMemcpyDeviceToHost, b.stream));
     return HK_OK;
+}
+
+int run_moments(hk::EmBatch &b, const std::vector<int> &act, int what) {
+    long entries = 0;
+    int rc = stage_arcs(b, act, entries);
+    if (rc != HK_OK) return rc;
+    if (b.rows == 0) return HK_OK;
+    rc = upload_arcs(b, act.size(), entries);
+    if (rc != HK_OK) return rc;
+    rc = launch_moments(b, what);
+    if (rc != HK_OK) return rc;
+    HK_HIP(hipStreamSynchronize(b.stream));
+    return HK_OK;
+}
+
+// arc_out rows of a fit -> the arcs of the clips of the launch
+void apply_fit(hk::EmBatch &b, const std::vector<int> &act) {
+    for (size_t j = 0; j < act.size(); ++j) {
+        hk_clip &c = *b.clips[(size_t)act[j]];
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            const double *o = b.dev.h_arc_out + (b.arc_base[j] + (long)k) * AP;
+            if (o[0] == 0.0) continue;
+            hk::Arc &arc = c.arcs[k];
+            arc.a = o[1]; arc.b = o[2]; arc.c = o[3]; arc.e = o[4];
+            arc.f_peak = o[5];
+        }
+    }
 }
 
 }  // namespace
 
 namespace hk {
 
-// Device workspaces outlive the clips that use them: hipMalloc / hipFree
+// Device workspaces outlive the batches that use them: hipMalloc / hipFree
 // (the latter synchronises the whole device) cost more than a whole EM pass
 // on a clip, so a released workspace is parked here, per device, and the next
-// clip on that device takes it over.  hk_release_cached_memory() frees them.
-// As many are kept as clips can be in steps 3-4 at a time in a pipelined batch
-// (one per builder thread, up to ~30 with more cores per GPU): with fewer, a
-// batch frees and allocates workspaces all the time, and every hipFree holds
-// up the detection thread's launches for milliseconds.  A workspace of a
-// 50 000-tag clip is a few MB.
+// batch on that device takes it over.  hk_release_cached_memory() frees them.
+// A workspace of a 50 000-tag clip is a few MB.
 namespace {
 constexpr size_t POOL_MAX = 48;
 std::mutex g_pool_mutex;
 std::vector<DeviceState> g_pool;
 
-// The tag uploads of em_prepare() are asynchronous copies out of the
-// workspace's pinned block.  A clip without arcs never synchronises its
-// stream (every EM call returns early), and an error path may skip the wait
-// too: before the workspace is parked, freed or its block refilled, the copies
-// must have left it -- otherwise the next owner, on another stream, could
-// overwrite h_tags under them or see its own uploads overtaken by them.
+// The tag uploads of em_open() are asynchronous copies out of the workspace's
+// pinned block.  A batch without arcs never synchronises its stream (every EM
+// call returns early), and an error path may skip the wait too: before the
+// workspace is parked, freed or its block refilled, the copies must have left
+// it -- otherwise the next owner, on another stream, could overwrite h_tags
+// under them or see its own uploads overtaken by them.
 void wait_for_uploads(DeviceState &d) {
     if (!d.upload_pending || !d.uploaded) return;
     DeviceGuard guard(d.device);
@@ -481,10 +580,12 @@ void free_workspace(DeviceState &d) {
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
     (void)hipHostFree(d.h_tags);
     (void)hipFree(d.arc_params); (void)hipFree(d.arc_win);
-    (void)hipFree(d.arc_out); (void)hipFree(d.weights);
+    (void)hipFree(d.arc_out); (void)hipFree(d.arc_clip);
+    (void)hipFree(d.clip_tab); (void)hipFree(d.weights);
     (void)hipFree(d.bitmap); (void)hipFree(d.list); (void)hipFree(d.list_out);
     (void)hipHostFree(d.h_arc_params); (void)hipHostFree(d.h_arc_win);
-    (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_bitmap);
+    (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_arc_clip);
+    (void)hipHostFree(d.h_clip_tab); (void)hipHostFree(d.h_bitmap);
     (void)hipHostFree(d.h_list); (void)hipHostFree(d.h_list_out);
     (void)hipFree(d.merge_buf); (void)hipHostFree(d.h_merge_buf);
     d = DeviceState();
@@ -510,91 +611,149 @@ int ensure_tag_capacity(DeviceState &d, int n) {
     d.tag_cap = (int)cap;
     return HK_OK;
 }
+
+// The tags of all clips of the batch, end to end, on their way to the device.
+int upload_tags(EmBatch &b) {
+    DeviceState &d = b.dev;
+    const hipStream_t s = b.stream;
+    const int rc = ensure_tag_capacity(d, d.n);
+    if (rc != HK_OK) return rc;
+    wait_for_uploads(d);        // (a workspace that em_close parked has none)
+    const size_t n = (size_t)d.n;
+    if (n == 0) return HK_OK;
+    // Through the workspace's pinned block: a copy from the clips' pageable
+    // vectors is a synchronous call of ~0.2 ms each that holds up other
+    // threads' launches (seen in a HIP API trace of a batch).  The block is
+    // the workspace's own; an event behind the copies is waited for before
+    // the workspace is handed on (wait_for_uploads).
+    if (!d.uploaded) {
+        hipEvent_t ev = nullptr;
+        HK_HIP(hipEventCreateWithFlags(
+            &ev, hipEventDisableTiming | hipEventBlockingSync));
+        d.uploaded = ev;
+    }
+    const size_t cap = (size_t)d.tag_cap;
+    double *hx = reinterpret_cast<double *>(d.h_tags);
+    double *hy = hx + cap, *hr = hy + cap, *htw = hr + cap;
+    int *hf = reinterpret_cast<int *>(htw + cap);
+    for (size_t k = 0; k < b.clips.size(); ++k) {
+        const hk_clip &c = *b.clips[k];
+        const size_t at = (size_t)b.tag_base[k], m = (size_t)c.n;
+        if (m == 0) continue;
+        std::memcpy(hx + at, c.x.data(), sizeof(double) * m);
+        std::memcpy(hy + at, c.y.data(), sizeof(double) * m);
+        std::memcpy(hr + at, c.r.data(), sizeof(double) * m);
+        std::memcpy(htw + at, c.tw.data(), sizeof(double) * m);
+        std::memcpy(hf + at, c.frame.data(), sizeof(int) * m);
+    }
+    // (pending from the first copy on, so that an error half-way still waits:
+    // the event then completes at once or behind what was queued)
+    d.upload_pending = true;
+    hipError_t e = hipMemcpyAsync(d.frame, hf, sizeof(int) * n,
+                                  hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d.x, hx, sizeof(double) * n, hipMemcpyHostToDevice,
+                           s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d.y, hy, sizeof(double) * n, hipMemcpyHostToDevice,
+                           s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d.r, hr, sizeof(double) * n, hipMemcpyHostToDevice,
+                           s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d.tw, htw, sizeof(double) * n,
+                           hipMemcpyHostToDevice, s);
+    const hipError_t e2 = hipEventRecord((hipEvent_t)d.uploaded, s);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(s);
+        d.upload_pending = false;
+        HK_HIP(e);
+    }
+    return HK_OK;
+}
 }  // namespace
 
-int em_prepare(hk_clip &c, hipStream_t s) {
-    DeviceState &d = c.dev;
-    if (d.ready) return HK_OK;
-    DeviceGuard guard(c.device);
-    if (!guard.ok)
-        return fail(HK_ERR_HIP, "cannot select device %d", c.device);
-    if (!d.tag_cap && !d.arc_cap) {         // take over a parked workspace
+int em_open(hk_clip *const *clips, int n, hipStream_t s, EmBatch **out) {
+    *out = nullptr;
+    if (n <= 0) return fail(HK_ERR_ARG, "EM batch without clips");
+    const int device = clips[0]->device;
+    long total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (clips[k]->device != device)
+            return fail(HK_ERR_ARG, "the clips of an EM batch must be on one "
+                                    "device (%d and %d)", device,
+                        clips[k]->device);
+        total += clips[k]->n;
+    }
+    if (total > (1L << 30))
+        return fail(HK_ERR_CAPACITY, "EM batch of %ld tags", total);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(HK_ERR_HIP, "cannot select device %d", device);
+    EmBatch *b = new EmBatch();
+    b->clips.assign(clips, clips + n);
+    b->device = device;
+    b->stream = s;
+    b->tag_base.resize((size_t)n);
+    int at = 0;
+    for (int k = 0; k < n; ++k) {
+        b->tag_base[(size_t)k] = at;
+        at += clips[k]->n;
+    }
+    {                                       // take over a parked workspace
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         for (size_t i = 0; i < g_pool.size(); ++i)
-            if (g_pool[i].device == c.device) {
-                d = g_pool[i];
+            if (g_pool[i].device == device) {
+                b->dev = g_pool[i];
                 g_pool.erase(g_pool.begin() + (long)i);
                 break;
             }
     }
-    d.device = c.device;
-    d.n = c.n;
-    const int rc = ensure_tag_capacity(d, c.n);
-    if (rc != HK_OK) return rc;
-    const size_t n = (size_t)c.n;
-    wait_for_uploads(d);        // (a workspace that em_release parked has none)
-    if (n) {
-        // Through the workspace's pinned block: a copy from the clip's
-        // pageable vectors is a synchronous call of ~0.2 ms each that holds
-        // up other threads' launches (seen in a HIP API trace of a batch).
-        // The block is the workspace's own; an event behind the copies is
-        // waited for before the workspace is handed on (wait_for_uploads).
-        if (!d.uploaded) {
-            hipEvent_t ev = nullptr;
-            HK_HIP(hipEventCreateWithFlags(
-                &ev, hipEventDisableTiming | hipEventBlockingSync));
-            d.uploaded = ev;
-        }
-        const size_t cap = (size_t)d.tag_cap;
-        double *hx = reinterpret_cast<double *>(d.h_tags);
-        double *hy = hx + cap, *hr = hy + cap, *htw = hr + cap;
-        int *hf = reinterpret_cast<int *>(htw + cap);
-        std::memcpy(hx, c.x.data(), sizeof(double) * n);
-        std::memcpy(hy, c.y.data(), sizeof(double) * n);
-        std::memcpy(hr, c.r.data(), sizeof(double) * n);
-        std::memcpy(htw, c.tw.data(), sizeof(double) * n);
-        std::memcpy(hf, c.frame.data(), sizeof(int) * n);
-        HK_HIP(hipMemcpyAsync(d.frame, hf, sizeof(int) * n,
-                              hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.x, hx, sizeof(double) * n,
-                              hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.y, hy, sizeof(double) * n,
-                              hipMemcpyHostToDevice, s));
-        HK_HIP(hipMemcpyAsync(d.r, hr, sizeof(double) * n,
-                              hipMemcpyHostToDevice, s));
-        // (pending from the first copy on, so that an error half-way still
-        // waits: the event then completes at once or behind what was queued)
-        d.upload_pending = true;
-        hipError_t e = hipMemcpyAsync(d.tw, htw, sizeof(double) * n,
-                                      hipMemcpyHostToDevice, s);
-        const hipError_t e2 = hipEventRecord((hipEvent_t)d.uploaded, s);
-        if (e == hipSuccess) e = e2;
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(s);
-            d.upload_pending = false;
-            HK_HIP(e);
-        }
+    b->dev.device = device;
+    b->dev.n = at;
+    const int rc = upload_tags(*b);
+    if (rc != HK_OK) {
+        em_close(b);
+        return rc;
     }
-    d.ready = true;
+    *out = b;
+    return HK_OK;
+}
+
+void em_close(EmBatch *b) {
+    if (!b) return;
+    DeviceState &d = b->dev;
+    const bool any = d.tag_cap || d.arc_cap || d.clip_cap || d.weight_cap ||
+                     d.bitmap_cap || d.list_cap || d.merge_cap || d.uploaded;
+    if (any) {
+        wait_for_uploads(d);
+        bool parked = false;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            if (g_pool.size() < POOL_MAX) {
+                g_pool.push_back(d);
+                parked = true;
+            }
+        }
+        if (!parked) free_workspace(d);
+    }
+    delete b;
+}
+
+int em_own(hk_clip &c, hipStream_t s, EmBatch **out) {
+    if (!c.own) {
+        hk_clip *one = &c;
+        const int rc = em_open(&one, 1, s, &c.own);
+        if (rc != HK_OK) return rc;
+    }
+    c.own->stream = s;
+    *out = c.own;
     return HK_OK;
 }
 
 void em_release(hk_clip &c) {
-    DeviceState &d = c.dev;
-    if (!d.tag_cap && !d.arc_cap && !d.weight_cap && !d.bitmap_cap &&
-        !d.list_cap && !d.merge_cap)
-        return;
-    d.ready = false;
-    wait_for_uploads(d);
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (g_pool.size() < POOL_MAX) {
-            g_pool.push_back(d);
-            d = DeviceState();
-            return;
-        }
-    }
-    free_workspace(d);
+    em_close(c.own);
+    c.own = nullptr;
 }
 
 void em_release_cached() {
@@ -606,178 +765,223 @@ void em_release_cached() {
     for (DeviceState &d : all) free_workspace(d);
 }
 
-int em_estep(hk_clip &c, hipStream_t s) {
-    DeviceState &d = c.dev;
-    DeviceGuard guard(c.device);
-    const int A = (int)c.arcs.size();
-    if (A == 0) return HK_OK;
-    int rc = ensure_arc_capacity(d, A);
+int em_estep(EmBatch &b, const std::vector<int> &act, bool fit_too) {
+    DeviceState &d = b.dev;
+    DeviceGuard guard(b.device);
+    const hipStream_t s = b.stream;
+    int rc = stage_clips(b, act);
     if (rc != HK_OK) return rc;
+    if (b.rows == 0) return HK_OK;
 
     // windows, radius gates and buffer offsets (host)
     long woff = 0, boff = 0;
-    const double rw = c.p.radius_window;
-    for (int k = 0; k < A; ++k) {
-        Arc &arc = c.arcs[k];
-        double *p = d.h_arc_params + (long)k * AP;
-        long *w = d.h_arc_win + (long)k * AW;
-        p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
-        p[4] = arc.f_peak; p[7] = 0.0;
-        int lo = 0, hi = 0;
-        if (!arc.tags.empty()) {
-            const double m = median_tag_radius(c, arc.tags);
-            p[5] = m * (1 - rw);
-            p[6] = m * (1 + rw);
-            int f_min, f_max;
-            arc_frame_range(c, arc, f_min, f_max);
-            if (f_max > f_min) {        // range(f_min, f_max): end exclusive
-                lo = c.start[f_min];
-                hi = c.start[f_max];
+    int max_tags = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        hk_clip &c = *b.clips[(size_t)act[j]];
+        const int base = b.tag_base[(size_t)act[j]];
+        const double rw = c.p.radius_window;
+        max_tags = std::max(max_tags, c.n);
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            Arc &arc = c.arcs[k];
+            const long row = b.arc_base[j] + (long)k;
+            double *p = d.h_arc_params + row * AP;
+            long *w = d.h_arc_win + row * AW;
+            p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
+            p[4] = arc.f_peak; p[7] = 0.0;
+            int lo = 0, hi = 0;
+            if (!arc.tags.empty()) {
+                const double m = median_tag_radius(c, arc.tags);
+                p[5] = m * (1 - rw);
+                p[6] = m * (1 + rw);
+                int f_min, f_max;
+                arc_frame_range(c, arc, f_min, f_max);
+                if (f_max > f_min) {    // range(f_min, f_max): end exclusive
+                    lo = c.start[f_min];
+                    hi = c.start[f_max];
+                }
+            } else {
+                p[5] = p[6] = 0.0;
             }
-        } else {
-            p[5] = p[6] = 0.0;
+            arc.w_lo = lo;
+            arc.w_hi = hi;
+            arc.w_off = woff;
+            w[0] = base + lo; w[1] = base + hi; w[2] = woff; w[3] = boff;
+            woff += hi - lo;
+            boff += ((hi - lo) + 63) / 64;
         }
-        arc.w_lo = lo;
-        arc.w_hi = hi;
-        arc.w_off = woff;
-        w[0] = lo; w[1] = hi; w[2] = woff; w[3] = boff;
-        woff += hi - lo;
-        boff += ((hi - lo) + 63) / 64;
     }
     rc = ensure_weight_capacity(d, woff, boff);
     if (rc != HK_OK) return rc;
-    rc = upload_arcs(c, 0, s);
+    rc = upload_arcs(b, act.size(), 0);
     if (rc != HK_OK) return rc;
 
-    const Rot rot = rotation(c);
+    const unsigned A = (unsigned)b.rows;
     const TagArrays tg = tag_arrays(d);
     hipLaunchKernelGGL(estep_raw_k, dim3(A), dim3(256), 0, s, tg, d.arc_params,
-                       d.arc_win, d.weights, rot.s, rot.c, c.p.sigmasq);
+                       d.arc_win, d.weights, d.arc_clip, d.clip_tab);
     HK_LAUNCH_CHECK("estep_raw_k");
-    if (c.n > 0) {
-        hipLaunchKernelGGL(estep_total_k, dim3((c.n + 255) / 256), dim3(256),
-                           0, s, c.n, A, d.arc_win, d.weights, d.total);
+    if (max_tags > 0) {
+        hipLaunchKernelGGL(estep_total_k,
+                           dim3((unsigned)((max_tags + 255) / 256),
+                                (unsigned)act.size()),
+                           dim3(256), 0, s, d.clip_tab, d.arc_win, d.weights,
+                           d.total);
         HK_LAUNCH_CHECK("estep_total_k");
     }
     hipLaunchKernelGGL(estep_norm_k, dim3(A), dim3(256), 0, s, tg, d.arc_win,
-                       d.weights, d.total,
-                       (unsigned long long *)d.bitmap);
+                       d.weights, d.total, (unsigned long long *)d.bitmap);
     HK_LAUNCH_CHECK("estep_norm_k");
     if (boff > 0)
         HK_HIP(hipMemcpyAsync(d.h_bitmap, d.bitmap, sizeof(uint64_t) * boff,
                               hipMemcpyDeviceToHost, s));
+    if (fit_too) {
+        // the M-step reads the arc tables as they stand (the E-step does not
+        // change the parameters) and the weights where the E-step left them
+        rc = launch_moments(b, 0);
+        if (rc != HK_OK) return rc;
+    }
     HK_HIP(hipStreamSynchronize(s));
 
     // arc.tags <- membership bits (ascending by construction)
-    for (int k = 0; k < A; ++k) {
-        Arc &arc = c.arcs[k];
-        arc.tags.clear();
-        const long *w = d.h_arc_win + (long)k * AW;
-        const long words = ((w[1] - w[0]) + 63) / 64;
-        for (long j = 0; j < words; ++j) {
-            uint64_t bits = d.h_bitmap[w[3] + j];
-            while (bits) {
-                const int b = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                arc.tags.push_back((int)(w[0] + j * 64 + b));
+    for (size_t j = 0; j < act.size(); ++j) {
+        hk_clip &c = *b.clips[(size_t)act[j]];
+        const int base = b.tag_base[(size_t)act[j]];
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            Arc &arc = c.arcs[k];
+            arc.tags.clear();
+            const long *w = d.h_arc_win + (b.arc_base[j] + (long)k) * AW;
+            const long words = ((w[1] - w[0]) + 63) / 64;
+            for (long q = 0; q < words; ++q) {
+                uint64_t bits = d.h_bitmap[w[3] + q];
+                while (bits) {
+                    const int bit = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    arc.tags.push_back((int)(w[0] - base + q * 64 + bit));
+                }
             }
         }
     }
+    if (fit_too) apply_fit(b, act);
     return HK_OK;
 }
 
-int em_fit(hk_clip &c, hipStream_t s) {
-    DeviceGuard guard(c.device);
-    const int rc = run_moments(c, s, 0);
+int em_fit(EmBatch &b, const std::vector<int> &act) {
+    DeviceGuard guard(b.device);
+    const int rc = run_moments(b, act, 0);
     if (rc != HK_OK) return rc;
-    for (size_t k = 0; k < c.arcs.size(); ++k) {
-        const double *o = c.dev.h_arc_out + (long)k * AP;
-        if (o[0] == 0.0) continue;
-        Arc &arc = c.arcs[k];
-        arc.a = o[1]; arc.b = o[2]; arc.c = o[3]; arc.e = o[4];
-        arc.f_peak = o[5];
-    }
+    if (b.rows > 0) apply_fit(b, act);
     return HK_OK;
 }
 
-int em_tilt(hk_clip &c, hipStream_t s) {
-    DeviceGuard guard(c.device);
-    const int rc = run_moments(c, s, 1);
+int em_tilt(EmBatch &b, const std::vector<int> &act) {
+    DeviceGuard guard(b.device);
+    const int rc = run_moments(b, act, 1);
     if (rc != HK_OK) return rc;
-    double sum = 0.0;
-    int count = 0;
-    for (size_t k = 0; k < c.arcs.size(); ++k) {
-        const double *o = c.dev.h_arc_out + (long)k * AP;
-        if (o[0] == 0.0) continue;
-        const double e_x = o[1], e_y = o[2];
-        if (acceleration_ok(c, e_y)) {
-            sum += std::atan(e_x / e_y);
-            ++count;
+    for (size_t j = 0; j < act.size(); ++j) {
+        hk_clip &c = *b.clips[(size_t)act[j]];
+        double sum = 0.0;
+        int count = 0;
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            const double *o = b.dev.h_arc_out + (b.arc_base[j] + (long)k) * AP;
+            if (o[0] == 0.0) continue;
+            const double e_x = o[1], e_y = o[2];
+            if (acceleration_ok(c, e_y)) {
+                sum += std::atan(e_x / e_y);
+                ++count;
+            }
         }
+        c.tilt = count > 0 ? sum / count : 0.0;
     }
-    c.tilt = count > 0 ? sum / count : 0.0;
     return HK_OK;
 }
 
-int em_member_distances(hk_clip &c, hipStream_t s, std::vector<double> &dist,
-                        std::vector<long> &offsets) {
-    DeviceState &d = c.dev;
-    DeviceGuard guard(c.device);
-    const int A = (int)c.arcs.size();
-    offsets.assign((size_t)A + 1, 0);
-    long total = 0;
-    for (int k = 0; k < A; ++k) {
-        offsets[k] = total;
-        total += (long)c.arcs[k].tags.size();
-    }
-    offsets[A] = total;
-    dist.assign((size_t)total, 0.0);
-    if (A == 0 || total == 0) return HK_OK;
-    int rc = ensure_arc_capacity(d, A);
+int em_member_distances(EmBatch &b, const std::vector<int> &act,
+                        std::vector<std::vector<double>> &dist,
+                        std::vector<std::vector<long>> &offsets) {
+    DeviceState &d = b.dev;
+    DeviceGuard guard(b.device);
+    dist.assign(act.size(), std::vector<double>());
+    offsets.assign(act.size(), std::vector<long>());
+    int rc = stage_clips(b, act);
     if (rc != HK_OK) return rc;
+    long total = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const hk_clip &c = *b.clips[(size_t)act[j]];
+        std::vector<long> &off = offsets[j];
+        off.assign(c.arcs.size() + 1, 0);
+        long mine = 0;
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            off[k] = mine;
+            mine += (long)c.arcs[k].tags.size();
+        }
+        off[c.arcs.size()] = mine;
+        dist[j].assign((size_t)mine, 0.0);
+        total += mine;
+    }
+    if (b.rows == 0 || total == 0) return HK_OK;
     rc = ensure_list_capacity(d, total);
     if (rc != HK_OK) return rc;
-    for (int k = 0; k < A; ++k) {
-        const Arc &arc = c.arcs[k];
-        double *p = d.h_arc_params + (long)k * AP;
-        p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
-        p[4] = arc.f_peak; p[5] = p[6] = p[7] = 0.0;
-        long *w = d.h_arc_win + (long)k * AW;
-        w[0] = offsets[k]; w[1] = offsets[k + 1]; w[2] = -1; w[3] = 0;
-        std::copy(arc.tags.begin(), arc.tags.end(), d.h_list + offsets[k]);
+    long pos = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const hk_clip &c = *b.clips[(size_t)act[j]];
+        const int base = b.tag_base[(size_t)act[j]];
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            const Arc &arc = c.arcs[k];
+            const long row = b.arc_base[j] + (long)k;
+            double *p = d.h_arc_params + row * AP;
+            p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
+            p[4] = arc.f_peak; p[5] = p[6] = p[7] = 0.0;
+            long *w = d.h_arc_win + row * AW;
+            w[0] = pos;
+            for (int i : arc.tags) d.h_list[pos++] = base + i;
+            w[1] = pos; w[2] = -1; w[3] = 0;
+        }
     }
-    rc = upload_arcs(c, total, s);
+    rc = upload_arcs(b, act.size(), total);
     if (rc != HK_OK) return rc;
-    const Rot rot = rotation(c);
-    hipLaunchKernelGGL(member_dist_k, dim3(A), dim3(64), 0, s, tag_arrays(d),
-                       d.arc_params, d.arc_win, d.list, d.list_out, rot.s,
-                       rot.c);
+    hipLaunchKernelGGL(member_dist_k, dim3((unsigned)b.rows), dim3(64), 0,
+                       b.stream, tag_arrays(d), d.arc_params, d.arc_win, d.list,
+                       d.list_out, d.arc_clip, d.clip_tab);
     HK_LAUNCH_CHECK("member_dist_k");
     HK_HIP(hipMemcpyAsync(d.h_list_out, d.list_out, sizeof(double) * total,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipStreamSynchronize(s));
-    std::copy(d.h_list_out, d.h_list_out + total, dist.begin());
+                          hipMemcpyDeviceToHost, b.stream));
+    HK_HIP(hipStreamSynchronize(b.stream));
+    pos = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        std::copy(d.h_list_out + pos, d.h_list_out + pos + (long)dist[j].size(),
+                  dist[j].begin());
+        pos += (long)dist[j].size();
+    }
     return HK_OK;
 }
 
-// All candidate pairs of a merge pass in one launch.  good_off/good: the
-// arcs' good-tag lists (CSR over the current arc list); pairs: (i1, i2)
-// positions in that list.
-int em_merge_trials(hk_clip &c, hipStream_t s, const std::vector<int> &good_off,
-                    const std::vector<int> &good, const std::vector<int> &pairs,
-                    std::vector<MergeTrial> &out) {
-    DeviceState &d = c.dev;
-    DeviceGuard guard(c.device);
-    const size_t A = c.arcs.size();
-    const size_t npairs = pairs.size() / 2;
-    out.resize(npairs);
+// All candidate pairs of a merge pass of every clip of `act` in one launch.
+int em_merge_trials(EmBatch &b, const std::vector<int> &act,
+                    const std::vector<MergeInput> &in,
+                    std::vector<std::vector<MergeTrial>> &out) {
+    DeviceState &d = b.dev;
+    DeviceGuard guard(b.device);
+    out.assign(act.size(), std::vector<MergeTrial>());
+    int rc = stage_clips(b, act);
+    if (rc != HK_OK) return rc;
+    size_t npairs = 0, ngood = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        out[j].resize(in[j].pairs.size() / 2);
+        npairs += in[j].pairs.size() / 2;
+        ngood += in[j].good.size();
+    }
     if (npairs == 0) return HK_OK;
-    // one staging block: params | good_off | good | pairs, then the results
-    const size_t b_params = 0;
+    const size_t A = (size_t)b.rows;
+    // one staging block: clip table | arc_clip | params | good_off | good |
+    // pairs, then the results
+    const size_t b_clip = 0;
+    const size_t b_aclip = b_clip + sizeof(ClipDev) * act.size();
+    size_t b_params = b_aclip + sizeof(int) * A;
+    b_params = (b_params + 7) & ~(size_t)7;
     const size_t b_off = b_params + sizeof(double) * 5 * A;
     const size_t b_good = b_off + sizeof(int) * (A + 1);
-    const size_t b_pairs = b_good + sizeof(int) * good.size();
-    size_t b_out = b_pairs + sizeof(int) * pairs.size();
+    const size_t b_pairs = b_good + sizeof(int) * ngood;
+    size_t b_out = b_pairs + sizeof(int) * 2 * npairs;
     b_out = (b_out + 15) & ~(size_t)15;
     const size_t total = b_out + sizeof(MergeTrial) * npairs;
     if (total > d.merge_cap) {
@@ -792,34 +996,54 @@ int em_merge_trials(hk_clip &c, hipStream_t s, const std::vector<int> &good_off,
         d.merge_cap = cap;
     }
     char *h = d.h_merge_buf;
+    std::memcpy(h + b_clip, d.h_clip_tab, sizeof(ClipDev) * act.size());
+    std::memcpy(h + b_aclip, d.h_arc_clip, sizeof(int) * A);
     double *hp = reinterpret_cast<double *>(h + b_params);
-    for (size_t k = 0; k < A; ++k) {
-        const Arc &arc = c.arcs[k];
-        hp[5 * k] = arc.a;
-        hp[5 * k + 1] = arc.b;
-        hp[5 * k + 2] = arc.c;
-        hp[5 * k + 3] = arc.e;
-        hp[5 * k + 4] = arc.f_peak;
+    int *hoff = reinterpret_cast<int *>(h + b_off);
+    int *hgood = reinterpret_cast<int *>(h + b_good);
+    int *hpairs = reinterpret_cast<int *>(h + b_pairs);
+    size_t g_at = 0, p_at = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        const hk_clip &c = *b.clips[(size_t)act[j]];
+        const int base = b.tag_base[(size_t)act[j]];
+        const int row0 = b.arc_base[j];
+        const bool used = !in[j].pairs.empty();
+        for (size_t k = 0; k < c.arcs.size(); ++k) {
+            const Arc &arc = c.arcs[k];
+            double *p = hp + 5 * ((size_t)row0 + k);
+            p[0] = arc.a; p[1] = arc.b; p[2] = arc.c; p[3] = arc.e;
+            p[4] = arc.f_peak;
+            // (a clip without pairs hands no lists over: empty ranges)
+            hoff[(size_t)row0 + k] =
+                (int)g_at + (used ? in[j].good_off[k] : 0);
+        }
+        if (!used) continue;
+        for (int i : in[j].good) hgood[g_at++] = base + i;
+        for (int r : in[j].pairs) hpairs[p_at++] = row0 + r;
     }
-    std::memcpy(h + b_off, good_off.data(), sizeof(int) * (A + 1));
-    std::memcpy(h + b_good, good.data(), sizeof(int) * good.size());
-    std::memcpy(h + b_pairs, pairs.data(), sizeof(int) * pairs.size());
-    HK_HIP(hipMemcpyAsync(d.merge_buf, h, b_out, hipMemcpyHostToDevice, s));
-    const Rot rot = rotation(c);
+    hoff[A] = (int)g_at;
+    HK_HIP(hipMemcpyAsync(d.merge_buf, h, b_out, hipMemcpyHostToDevice,
+                          b.stream));
     char *g = d.merge_buf;
     hipLaunchKernelGGL(merge_trials_k, dim3((unsigned)((npairs + 63) / 64)),
-                       dim3(64), 0, s, tag_arrays(d),
+                       dim3(64), 0, b.stream, tag_arrays(d),
                        reinterpret_cast<const double *>(g + b_params),
                        reinterpret_cast<const int *>(g + b_off),
                        reinterpret_cast<const int *>(g + b_good),
                        reinterpret_cast<const int *>(g + b_pairs), (int)npairs,
-                       reinterpret_cast<MergeTrial *>(g + b_out), rot.s, rot.c,
-                       c.p.max_distance_pixels, c.p.min_tags_per_arc);
+                       reinterpret_cast<MergeTrial *>(g + b_out),
+                       reinterpret_cast<const int *>(g + b_aclip),
+                       reinterpret_cast<const ClipDev *>(g + b_clip));
     HK_LAUNCH_CHECK("merge_trials_k");
     HK_HIP(hipMemcpyAsync(h + b_out, g + b_out, sizeof(MergeTrial) * npairs,
-                          hipMemcpyDeviceToHost, s));
-    HK_HIP(hipStreamSynchronize(s));
-    std::memcpy(out.data(), h + b_out, sizeof(MergeTrial) * npairs);
+                          hipMemcpyDeviceToHost, b.stream));
+    HK_HIP(hipStreamSynchronize(b.stream));
+    const MergeTrial *res = reinterpret_cast<const MergeTrial *>(h + b_out);
+    size_t at = 0;
+    for (size_t j = 0; j < act.size(); ++j) {
+        std::copy(res + at, res + at + out[j].size(), out[j].begin());
+        at += out[j].size();
+    }
     return HK_OK;
 }
 
@@ -828,10 +1052,10 @@ int em_merge_trials(hk_clip &c, hipStream_t s, const std::vector<int> &good_off,
 extern "C" int hk_clip_get_weights(hk_clip *c, int *tag, int *arc,
                                    double *weight, int cap, void *stream) {
     if (!c) return hk::fail(HK_ERR_ARG, "hk_clip_get_weights: null clip");
-    hk::DeviceState &d = c->dev;
-    if (!d.ready)
+    if (!c->own)
         return hk::fail(HK_ERR_ARG,
                         "hk_clip_get_weights: run calculate_weights first");
+    hk::DeviceState &d = c->own->dev;
     hk::DeviceGuard guard(c->device);
     int n = 0;
     std::vector<double> w;

@@ -332,6 +332,16 @@ int hk_step3_device_built(void);
 int hk_set_host_threads(int n);
 /* Step 4.  Synchronises `stream` as needed. */
 int hk_clip_em_optimize(hk_clip *c, void *stream);
+/* Step 4 of several clips (of one device) in lockstep: EM_optimize
+ * (tracker.py:912-990) runs once per clip in the reference; here every device
+ * phase -- tilt, M-step, member distances, merge trial fits, E-step -- is ONE
+ * launch over the arcs of all clips that are at that point of their loop
+ * (BASELINE configs[4]: "EM batched across clips"), while the order-dependent
+ * merge / prune / clean decisions stay per clip.  Each clip ends up exactly
+ * as hk_clip_em_optimize leaves it on its own.  hk_clip_em_optimize is the
+ * batch of one.  Clips that have run the single operations below are refused
+ * (HK_ERR_ARG). */
+int hk_clips_em_optimize(hk_clip *const *clips, int nclips, void *stream);
 
 /* Debug aid: with on != 0 (or HK_SELF_CHECK set in the environment) every
  * merge trial fit that step 4 takes from the device (K8) is recomputed on the
