@@ -338,6 +338,38 @@ class ClipScanner:
         self._stage(res, 'step4_cpu', time.thread_time() - c0)
         return res
 
+    def refine_arcs_many(self, pairs, em_stream=None):
+        """Step 4 of several clips together: `pairs` = [(result, clip)] as
+        build_arcs() returns them (all clips on this scanner's device).  The
+        EM kernels run once per phase over the arcs of all clips
+        (hk_clips_em_optimize); every result is what refine_arcs() gives for
+        the clip on its own.  Closes the clips."""
+        if em_stream is None:
+            em_stream = self._em_stream
+        t0 = time.perf_counter()
+        c0 = time.thread_time()
+        clips = [clip for _, clip in pairs]
+        try:
+            Clip.em_optimize_many(clips, stream=em_stream.cuda_stream)
+            for res, clip in pairs:
+                res.arc_params, res.arc_ids, res.arc_members = clip.arcs()
+                res.alive, res.final_arc = clip.tag_state()
+                st = clip.state()
+                res.camera_tilt = st['camera_tilt']
+                res.g_px_per_frame_sq = st['g_px_per_frame_sq']
+                res.cm_per_pixel = st['cm_per_pixel']
+        finally:
+            for clip in clips:
+                clip.close()
+        # a clip's share of the call
+        wall = (time.perf_counter() - t0) / len(pairs)
+        cpu = (time.thread_time() - c0) / len(pairs)
+        for res, _ in pairs:
+            self._stage(res, 'step4', wall)
+            self._stage(res, 'step4_cpu', cpu)
+            self._stage(res, 'step4_batch', len(pairs))
+        return [res for res, _ in pairs]
+
     @staticmethod
     def _stage(res, name, seconds):
         stages = getattr(res, 'stage_seconds', None) or {}
@@ -369,7 +401,11 @@ class ClipScanner:
         (hk_step3_help) instead of owning a share of a build."""
         if cores is None:
             cores = host_core_share()
-        return max(1, cores - 1), 1
+        # one core for the detection loop (and one for the step-4 thread where
+        # HK_EM_THREAD=1 asks for it: it sleeps through its stream waits, but
+        # its host work is ~5 ms per clip)
+        spare = 2 if os.environ.get('HK_EM_THREAD', '0') != '0' else 1
+        return max(1, cores - spare), 1
 
     def scan_many(self, clips, host_threads=None, builders=None, count=None,
                   lookahead=None):
@@ -405,6 +441,26 @@ class ClipScanner:
                 lanes = max(1, min(lanes, int(count)))
         detected = queue.Queue(maxsize=builders)
         built = queue.Queue(maxsize=builders)
+        # Step 4.  Default: every builder thread takes its clip on through
+        # step 4 (the host half of step 4, ~5 ms per clip, then runs on as
+        # many cores as there are builders), but all of them on ONE stream,
+        # the scanner's EM stream: with a stream per builder, 15 + 3 streams
+        # shared the 4 hardware queues, and an EM kernel that landed in the
+        # queue of the detection stream waited behind whole MOG launches --
+        # step 4 took 25 ms per clip inside a 60-clip batch, 12.5 ms on the
+        # shared stream (and detection 7.4 instead of 8.1 ms; MI355X, 16
+        # cores; HK_EM_SHARED_STREAM=0 for the old way).
+        # HK_EM_THREAD=1: the clips whose step 3 is complete go to ONE thread
+        # that runs step 4 of all that are waiting in lockstep, every EM
+        # kernel launched once over the arcs of all of them
+        # (hk_clips_em_optimize).  Same results; measured slower on 16 cores
+        # per GPU (the thread costs a builder, and the last clips of a batch
+        # queue up behind it: 148-154 k against 163-172 k frames/s over 20
+        # clips), so it is the option, not the default.
+        em_thread = os.environ.get('HK_EM_THREAD', '0') != '0'
+        em_max = max(1, int(os.environ.get('HK_EM_BATCH', '8')))
+        shared_em_stream = os.environ.get('HK_EM_SHARED_STREAM', '1') != '0'
+        refine_q = queue.Queue()
         stop = threading.Event()
         END = object()
 
@@ -517,7 +573,9 @@ class ClipScanner:
                 # a stream of that thread: the last clips of a batch finish
                 # step 3 close together, and their step 4s then run side by
                 # side instead of queueing up on one thread
-                em_stream = torch.cuda.Stream(device=self.device)
+                # (HK_EM_SHARED_STREAM=0: a stream per builder thread)
+                em_stream = self._em_stream if shared_em_stream else \
+                    torch.cuda.Stream(device=self.device)
                 while True:
                     item = next_clip()
                     if item is END:
@@ -533,6 +591,9 @@ class ClipScanner:
                     finally:
                         with lock:
                             building[0] -= 1
+                    if em_thread:
+                        refine_q.put((seq,) + done)
+                        continue
                     try:
                         done = self.refine_arcs(*done)
                     except BaseException as exc:    # noqa: B902
@@ -549,6 +610,60 @@ class ClipScanner:
                     if not nat.lib.hk_step3_help(HELP_SEEDS):
                         time.sleep(0.0005)
             finally:
+                if em_thread:
+                    refine_q.put(END)
+                else:
+                    put(built, END)
+
+        def em_stage():
+            """Takes the clips that have finished step 3 -- all that are
+            waiting, up to em_max -- through step 4 together."""
+            ended = 0
+            held = []           # native clips not yet closed
+            try:
+                torch.cuda.set_device(self.device)
+                em_stream = torch.cuda.Stream(device=self.device)
+                while ended < builders:
+                    items = []
+                    try:
+                        items.append(refine_q.get(timeout=0.05))
+                    except queue.Empty:
+                        if stop.is_set():
+                            break
+                        continue
+                    while len(items) < em_max:
+                        try:
+                            items.append(refine_q.get_nowait())
+                        except queue.Empty:
+                            break
+                    ended += sum(1 for it in items if it is END)
+                    items = [it for it in items if it is not END]
+                    if not items:
+                        continue
+                    held = [clip for _, _, clip in items]
+                    if stop.is_set():
+                        break
+                    try:
+                        self.refine_arcs_many([(res, clip)
+                                               for _, res, clip in items],
+                                              em_stream)
+                    except BaseException as exc:    # noqa: B902
+                        put(built, (min(seq for seq, _, _ in items), exc))
+                        return
+                    held = []
+                    for seq, res, _ in items:
+                        if not put(built, (seq, res)):
+                            return
+            finally:
+                for clip in held:
+                    clip.close()
+                while True:         # clips nobody will refine any more
+                    try:
+                        it = refine_q.get_nowait()
+                    except queue.Empty:
+                        break
+                    if it is not END:
+                        it[2].close()
                 put(built, END)
 
         if host_threads is None:    # builders given: share the cores out
@@ -558,6 +673,9 @@ class ClipScanner:
                                     daemon=True) for lane in range(lanes)] + \
             [threading.Thread(target=build_stage, daemon=True)
              for _ in range(builders)]
+        if em_thread:
+            workers.append(threading.Thread(target=em_stage, daemon=True))
+        enders = 1 if em_thread else builders
         for w in workers:
             w.start()
         waiting = {}            # seq -> built clip or exception, out of order
@@ -571,7 +689,7 @@ class ClipScanner:
                         raise item
                     want += 1
                     yield item
-                if ended == builders:
+                if ended == enders:
                     break
                 item = built.get()
                 if item is END:

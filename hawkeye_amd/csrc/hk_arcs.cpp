@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -2137,6 +2138,42 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
 // already on the device follow each other without a host round trip (the
 // M-step behind the E-step), and prune reads the distances the merge phase
 // fetched.
+// fn(j) for j = 0 .. n-1, the clips of a batch: their host phases are
+// independent, so with several clips each gets a thread of its own for the
+// phase (a batch is large exactly when many builds ended together, i.e. when
+// the cores that built them have just come free).  Inline for one clip, and
+// whenever a clip has a progress callback (which is owed the caller's
+// thread).  Returns the first failure, with its message in the caller's
+// error buffer.
+template <class Fn>
+static int for_each_clip(hk_clip *const *clips, const std::vector<int> &act,
+                         Fn &&fn) {
+    const size_t n = act.size();
+    bool inline_only = n < 2;
+    for (int ci : act) inline_only = inline_only || clips[ci]->progress;
+    if (inline_only) {
+        for (size_t j = 0; j < n; ++j) {
+            const int rc = fn(j);
+            if (rc != HK_OK) return rc;
+        }
+        return HK_OK;
+    }
+    std::vector<int> rcs(n, HK_OK);
+    std::vector<std::string> msgs(n);
+    auto run = [&](size_t j) {
+        rcs[j] = fn(j);
+        if (rcs[j] != HK_OK) msgs[j] = hk::error_buffer();
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(n - 1);
+    for (size_t j = 1; j < n; ++j) pool.emplace_back(run, j);
+    run(0);
+    for (std::thread &t : pool) t.join();
+    for (size_t j = 0; j < n; ++j)
+        if (rcs[j] != HK_OK) return hk::fail(rcs[j], "%s", msgs[j].c_str());
+    return HK_OK;
+}
+
 // own: the batch to work in (a clip's own batch of one, which may hold E-step
 // weights from hk_clip_calculate_weights), or null to open one for the call.
 static int em_optimize_batch(hk_clip *const *clips, int n, hipStream_t s,
@@ -2182,40 +2219,42 @@ static int em_optimize_batch(hk_clip *const *clips, int n, hipStream_t s,
             int r = hk::em_member_distances(*b, act, dist, off);
             if (r != HK_OK) return r;
             inputs.assign(act.size(), hk::MergeInput());
-            for (size_t j = 0; j < act.size(); ++j) {
+            r = for_each_clip(clips, act, [&](size_t j) {
                 hk::MergeWork &mw = work[(size_t)act[j]];
                 hk::merge_prepare(*clips[act[j]], dist[j], off[j], mw);
                 inputs[j] = mw.in;
-            }
+                return (int)HK_OK;
+            });
+            if (r != HK_OK) return r;
             r = hk::em_merge_trials(*b, act, inputs, trials);
-            for (size_t j = 0; j < act.size() && r == HK_OK; ++j) {
+            if (r != HK_OK) return r;
+            return for_each_clip(clips, act, [&](size_t j) {
                 bool merged = false;
-                r = hk::merge_scan(*clips[act[j]], work[(size_t)act[j]],
-                                   trials[j], merged);
-                again[j] = again[j] || merged;
-            }
-            return r;
+                const int r2 = hk::merge_scan(*clips[act[j]],
+                                              work[(size_t)act[j]], trials[j],
+                                              merged);
+                if (merged) again[j] = 1;
+                return r2;
+            });
         });
         rc = timed(4, rc, [&] {
-            int r = HK_OK;
-            for (size_t j = 0; j < act.size() && r == HK_OK; ++j) {
+            return for_each_clip(clips, act, [&](size_t j) {
                 bool pruned = false;
-                r = hk::prune_phase(*clips[act[j]],
-                                    work[(size_t)act[j]].adist, pruned);
-                again[j] = again[j] || pruned;
-            }
-            return r;
+                const int r2 = hk::prune_phase(
+                    *clips[act[j]], work[(size_t)act[j]].adist, pruned);
+                if (pruned) again[j] = 1;
+                return r2;
+            });
         });
         rc = timed(5, rc, [&] { return hk::em_estep(*b, act, true); });
         std::vector<int> next;
-        for (size_t j = 0; j < act.size() && rc == HK_OK; ++j) {
-            if (again[j]) {
-                next.push_back(act[j]);
-            } else {
-                rc = timed(6, rc, [&] { return hk::clean(*clips[act[j]]); });
-                finishing.push_back(act[j]);
-            }
-        }
+        for (size_t j = 0; j < act.size(); ++j)
+            (again[j] ? next : finishing).push_back(act[j]);
+        rc = timed(6, rc, [&] {
+            return for_each_clip(clips, finishing, [&](size_t j) {
+                return hk::clean(*clips[finishing[j]]);
+            });
+        });
         act.swap(next);
     }
     if (!own) hk::em_close(b);

@@ -49,6 +49,8 @@ struct DeviceState {
                                         // h_tags; waited for before the
                                         // workspace changes hands
     bool upload_pending = false;
+    void *waited = nullptr;             // hipEvent_t of the blocking stream
+                                        // waits (wait_for_stream)
     // per-launch arc tables (grown on demand)
     int arc_cap = 0;
     double *arc_params = nullptr;       // [arc_cap][8]

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -330,6 +331,29 @@ hipError_t pin_alloc(T *&p, size_t count) {
     return hipHostMalloc((void **)&p, sizeof(T) * (count ? count : 1));
 }
 
+// Waits for the batch's stream.  The thread SLEEPS (an event created for
+// blocking waits) instead of spinning as hipStreamSynchronize does: the waits
+// of step 4 are 0.1-1 ms each beside the MOG launches of a batch, a dozen per
+// clip, and the host cores are what bounds a batch -- a spinning wait takes
+// a core from a step-3 build.  HK_EM_SPIN=1: hipStreamSynchronize.
+int wait_for_stream(hk::EmBatch &b) {
+    static const bool spin = getenv("HK_EM_SPIN") != nullptr;
+    hk::DeviceState &d = b.dev;
+    if (spin) {
+        HK_HIP(hipStreamSynchronize(b.stream));
+        return HK_OK;
+    }
+    if (!d.waited) {
+        hipEvent_t ev = nullptr;
+        HK_HIP(hipEventCreateWithFlags(
+            &ev, hipEventDisableTiming | hipEventBlockingSync));
+        d.waited = ev;
+    }
+    HK_HIP(hipEventRecord((hipEvent_t)d.waited, b.stream));
+    HK_HIP(hipEventSynchronize((hipEvent_t)d.waited));
+    return HK_OK;
+}
+
 TagArrays tag_arrays(const hk::DeviceState &d) {
     return TagArrays{d.frame, d.x, d.y, d.r, d.tw};
 }
@@ -527,7 +551,7 @@ int run_moments(hk::EmBatch &b, const std::vector<int> &act, int what) {
     if (rc != HK_OK) return rc;
     rc = launch_moments(b, what);
     if (rc != HK_OK) return rc;
-    HK_HIP(hipStreamSynchronize(b.stream));
+    { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
     return HK_OK;
 }
 
@@ -576,6 +600,7 @@ void free_workspace(DeviceState &d) {
     DeviceGuard guard(d.device);
     wait_for_uploads(d);
     if (d.uploaded) (void)hipEventDestroy((hipEvent_t)d.uploaded);
+    if (d.waited) (void)hipEventDestroy((hipEvent_t)d.waited);
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
     (void)hipHostFree(d.h_tags);
@@ -840,7 +865,7 @@ int em_estep(EmBatch &b, const std::vector<int> &act, bool fit_too) {
         rc = launch_moments(b, 0);
         if (rc != HK_OK) return rc;
     }
-    HK_HIP(hipStreamSynchronize(s));
+    { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
 
     // arc.tags <- membership bits (ascending by construction)
     for (size_t j = 0; j < act.size(); ++j) {
@@ -945,7 +970,7 @@ int em_member_distances(EmBatch &b, const std::vector<int> &act,
     HK_LAUNCH_CHECK("member_dist_k");
     HK_HIP(hipMemcpyAsync(d.h_list_out, d.list_out, sizeof(double) * total,
                           hipMemcpyDeviceToHost, b.stream));
-    HK_HIP(hipStreamSynchronize(b.stream));
+    { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
     pos = 0;
     for (size_t j = 0; j < act.size(); ++j) {
         std::copy(d.h_list_out + pos, d.h_list_out + pos + (long)dist[j].size(),
@@ -1037,7 +1062,7 @@ int em_merge_trials(EmBatch &b, const std::vector<int> &act,
     HK_LAUNCH_CHECK("merge_trials_k");
     HK_HIP(hipMemcpyAsync(h + b_out, g + b_out, sizeof(MergeTrial) * npairs,
                           hipMemcpyDeviceToHost, b.stream));
-    HK_HIP(hipStreamSynchronize(b.stream));
+    { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
     const MergeTrial *res = reinterpret_cast<const MergeTrial *>(h + b_out);
     size_t at = 0;
     for (size_t j = 0; j < act.size(); ++j) {

@@ -290,3 +290,31 @@ def test_an_error_of_the_clip_iterator_loses_no_finished_clip():
     for a, b in zip(want, got):
         same_result(a, b)
     sc.close()
+
+
+@pytest.mark.parametrize('mode', ['em_thread', 'stream_per_builder'])
+def test_step4_modes_of_the_pipeline_give_the_same_results(mode, monkeypatch):
+    """scan_many with step 4 on one lockstep thread (hk_clips_em_optimize over
+    the clips that are waiting) and with a stream per builder thread, against
+    the default (builders run step 4 of their own clip on the shared EM
+    stream) and against clip-by-clip scanning."""
+    from hawkeye_amd.batch import ClipScanner
+    specs = [small_spec(4600 + i, balls=3 + i % 3, frames=120 + 10 * i)
+             for i in range(7)]
+    clips = [render(s) for s in specs]
+    torch.cuda.synchronize()
+    sc = ClipScanner(320, 240, specs[0]['fps'], device=0, chunk=64)
+    want = [sc.scan(c) for c in clips]
+    if mode == 'em_thread':
+        monkeypatch.setenv('HK_EM_THREAD', '1')
+        monkeypatch.setenv('HK_EM_BATCH', '4')
+    else:
+        monkeypatch.setenv('HK_EM_SHARED_STREAM', '0')
+    for _ in range(2):
+        got = list(sc.scan_many(iter(clips), builders=4))
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            same_result(a, b)
+    if mode == 'em_thread':
+        assert all(r.stage_seconds['step4_batch'] >= 1 for r in got)
+    sc.close()
