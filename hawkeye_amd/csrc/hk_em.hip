@@ -358,11 +358,19 @@ TagArrays tag_arrays(const hk::DeviceState &d) {
     return TagArrays{d.frame, d.x, d.y, d.r, d.tw};
 }
 
+// The per-launch tables (arc parameters, windows, member lists, the clip
+// table) and the small results (fit / tilt rows, distances, membership bits)
+// are NOT copied: they live in page-locked host memory, which the kernels
+// read and write directly (h_* and its device-side name are one pointer).  A
+// copy each way is a command of its own on the stream -- beside the MOG
+// launches of a batch, a copy kernel that has to find wave slots like any
+// other: five of them per phase were most of what step 4 cost under load.
+// The tables are a few KB; every entry is read once.  (The tags, the dense
+// E-step weights and the merge trials' inputs, which are read many times
+// over, stay in device memory.)
 int ensure_arc_capacity(hk::DeviceState &d, int narcs) {
     if (narcs <= d.arc_cap) return HK_OK;
     const int cap = std::max(256, narcs * 2);
-    (void)hipFree(d.arc_params); (void)hipFree(d.arc_win);
-    (void)hipFree(d.arc_out); (void)hipFree(d.arc_clip);
     (void)hipHostFree(d.h_arc_params); (void)hipHostFree(d.h_arc_win);
     (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_arc_clip);
     d.arc_params = nullptr; d.arc_win = nullptr; d.arc_out = nullptr;
@@ -370,14 +378,14 @@ int ensure_arc_capacity(hk::DeviceState &d, int narcs) {
     d.h_arc_params = nullptr; d.h_arc_win = nullptr; d.h_arc_out = nullptr;
     d.h_arc_clip = nullptr;
     d.arc_cap = 0;
-    HK_HIP(dev_alloc(d.arc_params, (size_t)cap * AP));
-    HK_HIP(dev_alloc(d.arc_win, (size_t)cap * AW));
-    HK_HIP(dev_alloc(d.arc_out, (size_t)cap * AP));
-    HK_HIP(dev_alloc(d.arc_clip, (size_t)cap));
     HK_HIP(pin_alloc(d.h_arc_params, (size_t)cap * AP));
     HK_HIP(pin_alloc(d.h_arc_win, (size_t)cap * AW));
     HK_HIP(pin_alloc(d.h_arc_out, (size_t)cap * AP));
     HK_HIP(pin_alloc(d.h_arc_clip, (size_t)cap));
+    d.arc_params = d.h_arc_params;
+    d.arc_win = d.h_arc_win;
+    d.arc_out = d.h_arc_out;
+    d.arc_clip = d.h_arc_clip;
     d.arc_cap = cap;
     return HK_OK;
 }
@@ -385,13 +393,12 @@ int ensure_arc_capacity(hk::DeviceState &d, int narcs) {
 int ensure_clip_capacity(hk::DeviceState &d, int nclips) {
     if (nclips <= d.clip_cap) return HK_OK;
     const int cap = std::max(16, nclips * 2);
-    (void)hipFree(d.clip_tab);
     (void)hipHostFree(d.h_clip_tab);
     d.clip_tab = nullptr;
     d.h_clip_tab = nullptr;
     d.clip_cap = 0;
-    HK_HIP(dev_alloc(d.clip_tab, (size_t)cap));
     HK_HIP(pin_alloc(d.h_clip_tab, (size_t)cap));
+    d.clip_tab = d.h_clip_tab;
     d.clip_cap = cap;
     return HK_OK;
 }
@@ -407,13 +414,12 @@ int ensure_weight_capacity(hk::DeviceState &d, long doubles, long words) {
     }
     if (words > d.bitmap_cap) {
         const long cap = std::max(words * 2, 1L << 12);
-        (void)hipFree(d.bitmap);
         (void)hipHostFree(d.h_bitmap);
         d.bitmap = nullptr;
         d.h_bitmap = nullptr;
         d.bitmap_cap = 0;
-        HK_HIP(dev_alloc(d.bitmap, (size_t)cap));
         HK_HIP(pin_alloc(d.h_bitmap, (size_t)cap));
+        d.bitmap = d.h_bitmap;
         d.bitmap_cap = cap;
     }
     return HK_OK;
@@ -422,15 +428,14 @@ int ensure_weight_capacity(hk::DeviceState &d, long doubles, long words) {
 int ensure_list_capacity(hk::DeviceState &d, long entries) {
     if (entries <= d.list_cap) return HK_OK;
     const long cap = std::max(entries * 2, 1L << 14);
-    (void)hipFree(d.list); (void)hipFree(d.list_out);
     (void)hipHostFree(d.h_list); (void)hipHostFree(d.h_list_out);
     d.list = nullptr; d.list_out = nullptr;
     d.h_list = nullptr; d.h_list_out = nullptr;
     d.list_cap = 0;
-    HK_HIP(dev_alloc(d.list, (size_t)cap));
-    HK_HIP(dev_alloc(d.list_out, (size_t)cap));
     HK_HIP(pin_alloc(d.h_list, (size_t)cap));
     HK_HIP(pin_alloc(d.h_list_out, (size_t)cap));
+    d.list = d.h_list;
+    d.list_out = d.h_list_out;
     d.list_cap = cap;
     return HK_OK;
 }
@@ -510,25 +515,6 @@ int stage_arcs(hk::EmBatch &b, const std::vector<int> &act,
     return HK_OK;
 }
 
-int upload_arcs(hk::EmBatch &b, size_t nclips, long list_entries) {
-    hk::DeviceState &d = b.dev;
-    const hipStream_t s = b.stream;
-    const size_t A = (size_t)b.rows;
-    if (A == 0) return HK_OK;
-    HK_HIP(hipMemcpyAsync(d.clip_tab, d.h_clip_tab, sizeof(hk::ClipDev) * nclips,
-                          hipMemcpyHostToDevice, s));
-    HK_HIP(hipMemcpyAsync(d.arc_clip, d.h_arc_clip, sizeof(int) * A,
-                          hipMemcpyHostToDevice, s));
-    HK_HIP(hipMemcpyAsync(d.arc_params, d.h_arc_params, sizeof(double) * A * AP,
-                          hipMemcpyHostToDevice, s));
-    HK_HIP(hipMemcpyAsync(d.arc_win, d.h_arc_win, sizeof(long) * A * AW,
-                          hipMemcpyHostToDevice, s));
-    if (list_entries > 0)
-        HK_HIP(hipMemcpyAsync(d.list, d.h_list, sizeof(int) * list_entries,
-                              hipMemcpyHostToDevice, s));
-    return HK_OK;
-}
-
 int launch_moments(hk::EmBatch &b, int what) {
     hk::DeviceState &d = b.dev;
     hipLaunchKernelGGL(arc_moments_k, dim3((unsigned)b.rows), dim3(64), 0,
@@ -536,9 +522,6 @@ int launch_moments(hk::EmBatch &b, int what) {
                        d.weights, d.list, d.arc_out, d.arc_clip, d.clip_tab,
                        what);
     HK_LAUNCH_CHECK("arc_moments_k");
-    HK_HIP(hipMemcpyAsync(d.h_arc_out, d.arc_out,
-                          sizeof(double) * (size_t)b.rows * AP,
-                          hipMemcpyDeviceToHost, b.stream));
     return HK_OK;
 }
 
@@ -547,8 +530,6 @@ int run_moments(hk::EmBatch &b, const std::vector<int> &act, int what) {
     int rc = stage_arcs(b, act, entries);
     if (rc != HK_OK) return rc;
     if (b.rows == 0) return HK_OK;
-    rc = upload_arcs(b, act.size(), entries);
-    if (rc != HK_OK) return rc;
     rc = launch_moments(b, what);
     if (rc != HK_OK) return rc;
     { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
@@ -604,10 +585,7 @@ void free_workspace(DeviceState &d) {
     (void)hipFree(d.frame); (void)hipFree(d.x); (void)hipFree(d.y);
     (void)hipFree(d.r); (void)hipFree(d.tw); (void)hipFree(d.total);
     (void)hipHostFree(d.h_tags);
-    (void)hipFree(d.arc_params); (void)hipFree(d.arc_win);
-    (void)hipFree(d.arc_out); (void)hipFree(d.arc_clip);
-    (void)hipFree(d.clip_tab); (void)hipFree(d.weights);
-    (void)hipFree(d.bitmap); (void)hipFree(d.list); (void)hipFree(d.list_out);
+    (void)hipFree(d.weights);
     (void)hipHostFree(d.h_arc_params); (void)hipHostFree(d.h_arc_win);
     (void)hipHostFree(d.h_arc_out); (void)hipHostFree(d.h_arc_clip);
     (void)hipHostFree(d.h_clip_tab); (void)hipHostFree(d.h_bitmap);
@@ -837,9 +815,6 @@ int em_estep(EmBatch &b, const std::vector<int> &act, bool fit_too) {
     }
     rc = ensure_weight_capacity(d, woff, boff);
     if (rc != HK_OK) return rc;
-    rc = upload_arcs(b, act.size(), 0);
-    if (rc != HK_OK) return rc;
-
     const unsigned A = (unsigned)b.rows;
     const TagArrays tg = tag_arrays(d);
     hipLaunchKernelGGL(estep_raw_k, dim3(A), dim3(256), 0, s, tg, d.arc_params,
@@ -856,9 +831,6 @@ int em_estep(EmBatch &b, const std::vector<int> &act, bool fit_too) {
     hipLaunchKernelGGL(estep_norm_k, dim3(A), dim3(256), 0, s, tg, d.arc_win,
                        d.weights, d.total, (unsigned long long *)d.bitmap);
     HK_LAUNCH_CHECK("estep_norm_k");
-    if (boff > 0)
-        HK_HIP(hipMemcpyAsync(d.h_bitmap, d.bitmap, sizeof(uint64_t) * boff,
-                              hipMemcpyDeviceToHost, s));
     if (fit_too) {
         // the M-step reads the arc tables as they stand (the E-step does not
         // change the parameters) and the weights where the E-step left them
@@ -962,14 +934,10 @@ int em_member_distances(EmBatch &b, const std::vector<int> &act,
             w[1] = pos; w[2] = -1; w[3] = 0;
         }
     }
-    rc = upload_arcs(b, act.size(), total);
-    if (rc != HK_OK) return rc;
     hipLaunchKernelGGL(member_dist_k, dim3((unsigned)b.rows), dim3(64), 0,
                        b.stream, tag_arrays(d), d.arc_params, d.arc_win, d.list,
                        d.list_out, d.arc_clip, d.clip_tab);
     HK_LAUNCH_CHECK("member_dist_k");
-    HK_HIP(hipMemcpyAsync(d.h_list_out, d.list_out, sizeof(double) * total,
-                          hipMemcpyDeviceToHost, b.stream));
     { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
     pos = 0;
     for (size_t j = 0; j < act.size(); ++j) {
@@ -1056,12 +1024,10 @@ int em_merge_trials(EmBatch &b, const std::vector<int> &act,
                        reinterpret_cast<const int *>(g + b_off),
                        reinterpret_cast<const int *>(g + b_good),
                        reinterpret_cast<const int *>(g + b_pairs), (int)npairs,
-                       reinterpret_cast<MergeTrial *>(g + b_out),
+                       reinterpret_cast<MergeTrial *>(h + b_out),
                        reinterpret_cast<const int *>(g + b_aclip),
                        reinterpret_cast<const ClipDev *>(g + b_clip));
     HK_LAUNCH_CHECK("merge_trials_k");
-    HK_HIP(hipMemcpyAsync(h + b_out, g + b_out, sizeof(MergeTrial) * npairs,
-                          hipMemcpyDeviceToHost, b.stream));
     { const int src = wait_for_stream(b); if (src != HK_OK) return src; }
     const MergeTrial *res = reinterpret_cast<const MergeTrial *>(h + b_out);
     size_t at = 0;
