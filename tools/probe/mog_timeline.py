@@ -23,7 +23,7 @@ from hawkeye_amd.detect import (BackgroundSubtractorMOG,  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else 'clip'
 which = [int(a) for a in sys.argv[2:]] or [2, 7, 14]
-CHUNK = 120
+CHUNK = int(os.environ.get("PROBE_CHUNK", "120"))
 spec = dict(synth.CLIPS['C_1080p60_9ball_noisy'])
 static = scene == 'static'
 if static:
