@@ -43,7 +43,7 @@ The JSON line also carries
                 is not what bounds it: the bound is VALU issue (one vector
                 instruction per 4 cycles per SIMD for the packed-f32, convert,
                 compare and 64-bit move instructions it is made of; measured,
-                profiles/r02_ubench_counters.csv).  achieved = VALU
+                profiles/r03_ubench_counters.csv).  achieved = VALU
                 instructions of a launch (SQ counters of the shipped kernel on
                 this clip, profiles/mog_issue.json) / launch time; peak = 1024
                 SIMDs x 2.4 GHz / 4.  The physical HBM rate (PMC traffic /
@@ -110,7 +110,11 @@ ALGO_BYTES_PER_PIXEL_FRAME = 324       # 3 in + 1 out + 160 model rd + 160 wr
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024                           # 256 CUs x 4
 NOMINAL_CLOCK_HZ = 2.4e9
-VALU_ISSUE_CYCLES = 4                  # profiles/r02_ubench_counters.csv
+VALU_ISSUE_CYCLES = 4                  # profiles/r03_ubench_counters.csv
+# issue cost by class on a busy SIMD, same calibration: packed f32, convert,
+# compare and 64-bit moves 4.1-4.4 cycles, plain 32-bit arithmetic 2.3-2.7,
+# transcendental 8.2
+CLASS_CYCLES = {'packed': 4.2, 'plain': 2.5, 'trans': 8.2}
 
 
 def cpu_baseline(spec, frames_dev, gpu_events, sample, threads):
@@ -271,6 +275,25 @@ def mog_roofline(launch_ms, alone_ms, launch_frames, px, scene):
         roof['salu_per_wave_frame'] = \
             counts['SQ_INSTS_SALU']['per_wave_frame']
         roof['valu_busy_under_profiler'] = counts['valu_busy']
+        # the same with every class at its own measured price instead of the
+        # 4-cycle upper bound: f32 add / mul / fma (packed in this kernel) and
+        # the byte converts at the packed price, transcendental ones at
+        # theirs, whatever is left (integer, compare, select, move, max) at
+        # the plain price -- a lower estimate of the issue cycles used
+        def per_wf(name):
+            return counts.get(name, {}).get('per_wave_frame', 0.0)
+        arith = per_wf('SQ_INSTS_VALU_ADD_F32') + \
+            per_wf('SQ_INSTS_VALU_MUL_F32') + \
+            per_wf('SQ_INSTS_VALU_FMA_F32') + per_wf('SQ_INSTS_VALU_CVT')
+        trans = per_wf('SQ_INSTS_VALU_TRANS_F32')
+        rest = max(0.0, per_wf('SQ_INSTS_VALU') - arith - trans)
+        cycles = CLASS_CYCLES['packed'] * arith + \
+            CLASS_CYCLES['trans'] * trans + CLASS_CYCLES['plain'] * rest
+        wave_frames = (issue or {}).get('wave_frames_per_launch', 0) * scale
+        if wave_frames:
+            roof['frac_class_priced'] = round(
+                cycles * wave_frames / (SIMDS * NOMINAL_CLOCK_HZ * sec), 4)
+            roof['class_prices_cycles'] = CLASS_CYCLES
     if traffic is not None and scene == 'clip':
         hbm = traffic['bytes_per_launch'] * scale
         roof['traffic'] = int(hbm)
@@ -278,8 +301,18 @@ def mog_roofline(launch_ms, alone_ms, launch_frames, px, scene):
         roof['hbm'] = {'achieved': round(hbm / sec / 1e9, 1),
                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': round(hbm / sec / 1e9 / HBM_PEAK_GBS, 4),
-                       'note': 'physical HBM bytes of a launch (PMC) / launch '
-                               'time: the second roof, not the binding one'}
+                       'over_fetch_of_frame_lines': 1.65,
+                       'note': 'bytes the L2 asked the fabric for (PMC) / '
+                               'launch time: the second roof.  Counter scale '
+                               'calibrated on this kernel\'s access shapes '
+                               '(profiles/r03_hbm_counter_calibration.csv): '
+                               'FETCH_SIZE counts a 128-byte request as 64 '
+                               'bytes for the frame loads and the plane '
+                               'loads alike (so it is doubled), WRITE_SIZE '
+                               'is exact; the four 96-byte row segments of '
+                               'a tile straddle 128-byte lines and the '
+                               'frame lines are requested 1.65 times over '
+                               '(Infinity-Cache hits included)'}
     algo = ALGO_BYTES_PER_PIXEL_FRAME * px * launch_frames
     roof['algorithmic'] = {
         'bytes_per_launch': int(algo),
@@ -300,12 +333,12 @@ def mog_roofline(launch_ms, alone_ms, launch_frames, px, scene):
                 'counts: SQ counters of this kernel on this clip '
                 '(profiles/mog_issue.json, tools/prof_mog_sq.sh); the 4 '
                 'cycles per instruction per SIMD: counters of pure '
-                'instruction streams (profiles/r02_ubench_counters.csv).  '
+                'instruction streams (profiles/r03_ubench_counters.csv).  '
                 'launch_ms = HIP events around the launches of the timed '
                 'region, on their stream: the blob kernels of the previous '
                 'chunk run beside them on another stream and share the '
                 'chip, as they do under rocprofv3\'s kernel trace of the '
-                'same command (profiles/r02_kernel_stats.csv); '
+                'same command (profiles/r03_kernel_stats.csv); '
                 'launch_ms_alone / frac_alone = the same launches with the '
                 'GPU to themselves (what the counter passes profile)'})
     return roof

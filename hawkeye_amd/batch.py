@@ -280,6 +280,11 @@ class ClipScanner:
         total = int(frames.shape[0])
         parts = max(1, -(-total // self.chunk))
         size = max(1, -(-total // parts))
+        # whole groups of 4 frames where the chunk length allows: what is
+        # left over of a launch goes through the frame-at-a-time kernel,
+        # which reads and writes the whole model for every frame
+        if ((size + 3) & ~3) <= self.chunk:
+            size = (size + 3) & ~3
         return (frames[s:s + size] for s in range(0, total, size))
 
     def _from_source(self, src):
