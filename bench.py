@@ -400,7 +400,7 @@ def run_clips(args, world, rank, local):
     # run one clip at a time and leave the builder threads' streams, the
     # pooled EM workspaces and the chip's clocks cold): batches of W clips
     # until `--preroll-seconds` have passed.  A fresh box gives 5-10 % less in
-    # its first second of pipelined work than afterwards (tools/probe_warm.py).
+    # its first second of pipelined work than afterwards (tools/probe/warm.py).
     preroll_t0 = time.perf_counter()
     preroll_clips = 0
     while args.warmup > 0 and \
@@ -412,7 +412,7 @@ def run_clips(args, world, rank, local):
             preroll_clips += 1
     preroll_s = time.perf_counter() - preroll_t0
     # (every 8th launch is bracketed by timing events: bracketing all of them
-    # slowed the timed region by 15 %, tools/probe_batch_stages.py)
+    # slowed the timed region by 15 %, tools/probe/batch_stages.py)
     scanner.detector.mog_timing = []
     scanner.detector.mog_timing_every = args.time_every
     stage_s = {'detect': 0.0, 'step3': 0.0, 'step4': 0.0, 'step3_cpu': 0.0,

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Per-clip stage times along a pipelined batch (ClipScanner.scan_many on the
 benchmark clip).  Not part of the product.
-    python3 tools/probe_batch_stages.py [clips]"""
+    python3 tools/probe/batch_stages.py [clips]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))))
 import torch                                            # noqa: E402
 if os.environ.get('PROBE_IMPORT_DIST'):
     import torch.distributed                            # noqa: E402,F401

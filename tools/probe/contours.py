@@ -2,13 +2,14 @@
 """What the border tracer is asked to do on the benchmark clip: per frame the
 number of border-start candidates (the scan kernel's local rule), the
 contours OpenCV's findContours returns (C oracle) and their lengths.
-Not part of the product.   python3 tools/probe_contours.py [first] [count]"""
+Not part of the product.   python3 tools/probe/contours.py [first] [count]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))))
 import torch                                            # noqa: E402
 
 from hawkeye_amd import synth                           # noqa: E402

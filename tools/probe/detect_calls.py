@@ -9,7 +9,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))))
 import torch                                            # noqa: E402
 
 from hawkeye_amd import _native as nat                  # noqa: E402

@@ -1,3 +1,10 @@
+"""How many frames of pre-roll a time segment's MOG model needs before its masks agree with the
+sequential run (multi-GPU segments).  Not part of the product.
+    python3 tools/probe/warmup.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))))
 import torch
 from hawkeye_amd import synth
 from hawkeye_amd.detect import BackgroundSubtractorMOG
