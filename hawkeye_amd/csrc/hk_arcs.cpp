@@ -21,6 +21,7 @@
 #include <memory>
 #include <limits>
 #include <mutex>
+#include <new>
 #include <thread>
 
 #include "hk_clip.h"
@@ -226,17 +227,49 @@ inline void cpu_relax() {
 // position through a ring of result slots.
 #ifdef HK_S3_PROF
 #include <x86intrin.h>
-struct S3Prof { unsigned long long cyc[8] = {0}, cnt[8] = {0}; };
-static S3Prof g_s3prof;         // single-thread measurements only
-#define S3P_T0 const unsigned long long s3p_t0 = __rdtsc()
-#define S3P_ADD(k) do { g_s3prof.cyc[k] += __rdtsc() - s3p_t0; ++g_s3prof.cnt[k]; } while (0)
-#define S3P_CNT(k, n) (g_s3prof.cnt[k] += (n))
-#define S3P_BUILD (g_s3prof.cyc[6] += __rdtsc() - s3p_t0)
+// Reading the time stamp counter costs tens of cycles (more in a VM), which
+// is what the sections measured take themselves: HK_S3_PHASE=k times section k
+// alone, so that the run's wall time stays honest and the section's cycles are
+// off by its own reads only (a section timed empty gives that overhead).
+struct S3Prof {
+    unsigned long long cyc[12] = {0}, cnt[12] = {0};
+    // how trials end, and the growth steps they took: 0 no tag near the
+    // two-point arc, 1 doomed, 2 e <= 0, 3 a member too far after a refit,
+    // 4 stopped growing with too few members, 5 eval_arc said no, 6 accepted
+    unsigned long long end_n[8] = {0}, end_steps[8] = {0};
+    unsigned long long hist[8][8] = {{0}};  // by log2-ish size class
+};
+static S3Prof g_s3prof;         // the sum over a pass's threads
+static const int g_s3_phase = getenv("HK_S3_PHASE") ? atoi(getenv("HK_S3_PHASE")) : -1;
+struct S3Scope {
+    S3Prof &p;
+    const int k;
+    const bool on;
+    const unsigned long long t0;
+    S3Scope(S3Prof &pp, int kk)
+        : p(pp), k(kk), on(g_s3_phase < 0 || g_s3_phase == kk),
+          t0(on ? __rdtsc() : 0) {}
+    ~S3Scope() {
+        if (on) p.cyc[k] += __rdtsc() - t0;
+        ++p.cnt[k];
+    }
+};
+// (used where `s` is the running thread's Scratch)
+#define S3P_SCOPE(k) S3Scope s3p_scope_##k(s.prof, k)
+#define S3P_T0(k) const bool s3p_on = g_s3_phase < 0 || g_s3_phase == (k); \
+    const unsigned long long s3p_t0 = s3p_on ? __rdtsc() : 0
+#define S3P_ADD(k) do { if (s3p_on) s.prof.cyc[k] += __rdtsc() - s3p_t0; ++s.prof.cnt[k]; } while (0)
+#define S3P_CNT(k, n) (s.prof.cnt[k] += (n))
+#define S3P_END(k, members) do { const unsigned long long st_ = (members) - 2; \
+    ++s.prof.end_n[k]; s.prof.end_steps[k] += st_; \
+    int cls_ = 0; while (cls_ < 7 && (4ull << cls_) <= st_) ++cls_; \
+    s.prof.hist[k][cls_] += st_; } while (0)
 #else
-#define S3P_T0 do {} while (0)
+#define S3P_SCOPE(k) do {} while (0)
+#define S3P_END(k, members) do {} while (0)
+#define S3P_T0(k) do {} while (0)
 #define S3P_ADD(k) do {} while (0)
 #define S3P_CNT(k, n) do {} while (0)
-#define S3P_BUILD do {} while (0)
 #endif
 
 // Full passes in progress that threads from outside may join
@@ -473,6 +506,13 @@ public:
         for (size_t k = 0; k < Q; ++k) {
             const int t1 = queue_[k];
             Slot &slot = slots_[k & (window_ - 1)];
+            {   // the slots were written by other cores: have the lines of
+                // the next ones on their way while this one is dealt with
+                __builtin_prefetch(&slots_[(k + 12) & (window_ - 1)]);
+                const Slot &soon = slots_[(k + 6) & (window_ - 1)];
+                if (soon.state.load(std::memory_order_acquire) == 1)
+                    __builtin_prefetch(soon.res.consulted.data());
+            }
             if (done_[t1].load(std::memory_order_relaxed)) {
                 // joined an arc meanwhile; whoever claimed k saw that too,
                 // or will; wait for the slot so that it can be recycled
@@ -506,7 +546,10 @@ public:
                     out.push_back(std::move(r.arc));
                     r.made = false;
                 }
-                done_[t1].store(1, std::memory_order_relaxed);
+                // (a seed that made no arc is "done" by its place in the
+                // queue -- is_done() -- and needs no flag: a store per seed
+                // into the flags every worker reads all the time cost a
+                // 16-thread build a third of its seed time in cache misses)
                 if (++since_progress >= 256) {
                     since_progress = 0;
                     rc = report_progress(c);
@@ -544,9 +587,26 @@ public:
                           dev_message_);
         }
         stat_busy_ms_ = 0;
+        stat_steps_ = stat_runs_ = 0;
         for (int t = 0; t < MAX_SEED_THREADS; ++t) {
             stat_busy_ms_ += scratch_[t].busy_ms;
+            stat_steps_ += scratch_[t].steps;
+            stat_runs_ += scratch_[t].runs;
             scratch_[t].busy_ms = 0;
+            scratch_[t].steps = scratch_[t].runs = 0;
+#ifdef HK_S3_PROF
+            for (int k = 0; k < 12; ++k) {
+                g_s3prof.cyc[k] += scratch_[t].prof.cyc[k];
+                g_s3prof.cnt[k] += scratch_[t].prof.cnt[k];
+            }
+            for (int k = 0; k < 8; ++k) {
+                g_s3prof.end_n[k] += scratch_[t].prof.end_n[k];
+                g_s3prof.end_steps[k] += scratch_[t].prof.end_steps[k];
+                for (int h = 0; h < 8; ++h)
+                    g_s3prof.hist[k][h] += scratch_[t].prof.hist[k][h];
+            }
+            scratch_[t].prof = S3Prof();
+#endif
         }
         return rc;
     }
@@ -612,9 +672,11 @@ public:
         return atoi(e) == 1 && n_ >= 4096;
     }
 
-    std::atomic<long> stat_dev_used_{0}, stat_dev_host_{0};
+    // (statistics the committer updates as it goes: a cache line of their
+    // own, away from the members every worker reads all the time)
+    alignas(128) std::atomic<long> stat_dev_used_{0}, stat_dev_host_{0};
 
-    long stat_stale_ = 0, stat_helped_ = 0;
+    long stat_stale_ = 0, stat_helped_ = 0, stat_steps_ = 0, stat_runs_ = 0;
     double stat_stale_ms_ = 0, stat_busy_ms_ = 0;
     bool collect_stats_ = false;       // HK_STEP3_STATS: time every seed
 
@@ -626,18 +688,96 @@ private:
             int seen, in_frontier;
         };
         std::vector<Marks> marks;
-        std::vector<int> taken, members, frontier, cand, order;
-        // the frontier tags' frame, x, y travel with them (no gathers in
-        // the distance loop)
-        std::vector<double> vel, mf, mx, my, fq, ff, fx, fy;
+        std::vector<int> taken, cand, order;
+        std::vector<double> vel;
+        // the tags the current run found "not done", collected here and
+        // handed to the result slot in one piece when the run ends: the slot
+        // is memory the committer polls and another thread wrote last
+        std::vector<int> consulted;
+        // The members of the trial arc, ascending tag order, with their
+        // frame, x, y alongside (what the fits and checks run over): they
+        // occupy [m_lo, m_hi) of arrays with room on both sides, because an
+        // arc mostly grows at its ends -- a new first member moves m_lo, not
+        // the members.
+        std::vector<int> mem_id;
+        std::vector<double> mem_f, mem_x, mem_y;
+        int m_lo = 0, m_hi = 0, m_centre = 0;
+        // The frontier: tag, frame, x, y (no gathers in the distance loop)
+        // and the squared distance of the last scan, nf entries in use.
+        std::vector<int> fr_id;
+        std::vector<double> fr_f, fr_x, fr_y, fr_q;
+        size_t nf = 0;
         int stamp = 0, run_stamp = 0;
         double busy_ms = 0;
+        long steps = 0, runs = 0;       // growth steps / seeds run (statistics)
+#ifdef HK_S3_PROF
+        S3Prof prof;
+#endif
         std::vector<std::unique_ptr<int[]>> chunks;
         size_t chunk_used = 0, chunk_index = 0;
         static constexpr size_t CHUNK = 1 << 16;
         void init(int n, int F) {
             marks.assign((size_t)n, Marks{0, 0});
             taken.assign((size_t)(F > 0 ? F : 1), 0);
+            // at most one member per frame; every insertion moves one end
+            // of the range by one, so F + 2 on either side is never left
+            m_centre = (F > 0 ? F : 1) + 2;
+            const size_t cap = 2 * (size_t)m_centre + 8;
+            mem_id.assign(cap, 0);
+            mem_f.assign(cap, 0.0);
+            mem_x.assign(cap, 0.0);
+            mem_y.assign(cap, 0.0);
+            if (fr_id.empty()) fr_resize(256);
+        }
+        void fr_resize(size_t cap) {
+            fr_id.resize(cap);
+            fr_f.resize(cap);
+            fr_x.resize(cap);
+            fr_y.resize(cap);
+            fr_q.resize(cap);
+        }
+        void fr_push(int j, double f, double x, double y) {
+            if (nf == fr_id.size()) fr_resize(2 * nf);
+            fr_id[nf] = j;
+            fr_f[nf] = f;
+            fr_x[nf] = x;
+            fr_y[nf] = y;
+            ++nf;
+        }
+        int member_count() const { return m_hi - m_lo; }
+        void members_clear() { m_lo = m_hi = m_centre; }
+        // keeps the ascending tag order (j is not a member yet)
+        void member_insert(int j, double f, double x, double y) {
+            int *id = mem_id.data();
+            int at;
+            if (m_hi == m_lo || j > id[m_hi - 1]) {
+                at = m_hi++;
+            } else if (j < id[m_lo]) {
+                at = --m_lo;
+            } else {
+                const int pos = (int)(std::upper_bound(id + m_lo, id + m_hi, j) - id);
+                if (pos - m_lo < m_hi - pos) {      // the front part is shorter
+                    const size_t cnt = (size_t)(pos - m_lo);
+                    std::memmove(id + m_lo - 1, id + m_lo, cnt * sizeof(int));
+                    for (std::vector<double> *v : {&mem_f, &mem_x, &mem_y})
+                        std::memmove(v->data() + m_lo - 1, v->data() + m_lo,
+                                     cnt * sizeof(double));
+                    --m_lo;
+                    at = pos - 1;
+                } else {
+                    const size_t cnt = (size_t)(m_hi - pos);
+                    std::memmove(id + pos + 1, id + pos, cnt * sizeof(int));
+                    for (std::vector<double> *v : {&mem_f, &mem_x, &mem_y})
+                        std::memmove(v->data() + pos + 1, v->data() + pos,
+                                     cnt * sizeof(double));
+                    ++m_hi;
+                    at = pos;
+                }
+            }
+            id[at] = j;
+            mem_f[(size_t)at] = f;
+            mem_x[(size_t)at] = x;
+            mem_y[(size_t)at] = y;
         }
         void pool_reset() {
             chunk_index = 0;
@@ -661,10 +801,30 @@ private:
             return p;
         }
     };
+    // Memory in whole cache lines of its own: the results of neighbouring
+    // queue positions are written by different threads at the same time.
+    template <class T>
+    struct LineAlloc {
+        using value_type = T;
+        LineAlloc() = default;
+        template <class U>
+        LineAlloc(const LineAlloc<U> &) {}
+        T *allocate(size_t n) {
+            const size_t bytes = (n * sizeof(T) + 127) / 128 * 128;
+            return static_cast<T *>(::operator new(bytes, std::align_val_t(128)));
+        }
+        void deallocate(T *p, size_t) {
+            ::operator delete(p, std::align_val_t(128));
+        }
+        template <class U>
+        bool operator==(const LineAlloc<U> &) const { return true; }
+        template <class U>
+        bool operator!=(const LineAlloc<U> &) const { return false; }
+    };
     struct SeedResult {
         bool made = false;
         // tags the run found "not done" and may have used for that reason
-        std::vector<int> consulted;
+        std::vector<int, LineAlloc<int>> consulted;
         Arc arc;
     };
     struct alignas(128) Slot {
@@ -955,9 +1115,7 @@ private:
         if (st != 2) {
             uint8_t expected = 0;
             if (nb_state_[i].compare_exchange_strong(expected, 1)) {
-                S3P_T0;
                 build_neighbors(i, s);
-                S3P_BUILD;
                 nb_state_[i].store(2, std::memory_order_release);
             } else {
                 while (nb_state_[i].load(std::memory_order_acquire) != 2)
@@ -1057,7 +1215,7 @@ private:
     static void consult(int j, Scratch &s, SeedResult &res) {
         if (s.marks[(size_t)j].seen != s.run_stamp) {
             s.marks[(size_t)j].seen = s.run_stamp;
-            res.consulted.push_back(j);
+            s.consulted.push_back(j);
         }
     }
 
@@ -1112,14 +1270,11 @@ private:
         if (done_[j].load(std::memory_order_relaxed)) return;
         if (m.seen != s.run_stamp) {
             m.seen = s.run_stamp;
-            res.consulted.push_back(j);
+            s.consulted.push_back(j);
         }
         m.in_frontier = s.stamp;
         const TagRec &t = tag_[(size_t)j];
-        s.frontier.push_back(j);
-        s.ff.push_back((double)g);
-        s.fx.push_back(t.x);
-        s.fy.push_back(t.y);
+        s.fr_push(j, (double)g, t.x, t.y);
     }
 
     void add_one_to_frontier(int j, int pos, Scratch &s, SeedResult &res) {
@@ -1130,15 +1285,12 @@ private:
             Scratch::Marks &m = s.marks[(size_t)j];
             if (m.seen != s.run_stamp) {
                 m.seen = s.run_stamp;
-                res.consulted.push_back(j);
+                s.consulted.push_back(j);
             }
             if (s.taken[t.frame] == s.stamp || m.in_frontier == s.stamp)
                 return;
             m.in_frontier = s.stamp;
-            s.frontier.push_back(j);
-            s.ff.push_back((double)t.frame);
-            s.fx.push_back(t.x);
-            s.fy.push_back(t.y);
+            s.fr_push(j, (double)t.frame, t.x, t.y);
         }
     }
 
@@ -1158,17 +1310,18 @@ private:
     // their y is e + that of their offsets, so e lies within
     // D +- maxd * sum |coefficients|; likewise that of x is 0 +- the same.
     bool doomed(const Scratch &s) const {
-        const size_t n = s.members.size();
+        const size_t n = (size_t)s.member_count();
         if (!prune_ok_ || n < 3) return false;
-        const size_t i1 = 0, i2 = n / 2, i3 = n - 1;
-        const double f1 = s.mf[i1], f2 = s.mf[i2], f3 = s.mf[i3];
+        const size_t i1 = (size_t)s.m_lo, i2 = i1 + n / 2, i3 = i1 + n - 1;
+        const double *const mf = s.mem_f.data();
+        const double f1 = mf[i1], f2 = mf[i2], f3 = mf[i3];
         const double c1 = 1.0 / ((f2 - f1) * (f3 - f1));
         const double c2 = 1.0 / ((f2 - f1) * (f3 - f2));
         const double c3 = 1.0 / ((f3 - f1) * (f3 - f2));
         if (!(c1 > 0 && c2 > 0 && c3 > 0)) return false;   // frames not distinct
         const double slack = maxd_ * (c1 + c2 + c3) * (1 + 1e-9) + 1e-12;
-        const double dy = s.my[i1] * c1 - s.my[i2] * c2 + s.my[i3] * c3;
-        const double dx = s.mx[i1] * c1 - s.mx[i2] * c2 + s.mx[i3] * c3;
+        const double dy = s.mem_y[i1] * c1 - s.mem_y[i2] * c2 + s.mem_y[i3] * c3;
+        const double dx = s.mem_x[i1] * c1 - s.mem_x[i2] * c2 + s.mem_x[i3] * c3;
         if (!(dy == dy) || !(dx == dx)) return false;       // NaN coordinates
         const double tol = 1e-9 * (std::fabs(dy) + std::fabs(dx) + 1.0);
         if (dy + slack + tol < e_lo_) return true;
@@ -1200,13 +1353,16 @@ private:
     // fit_one() for unit weights over the member arrays (1.0 * v == v, so
     // the weight factors drop out bit for bit).
     void fit_members(Arc &arc, const Scratch &s) const {
-        const size_t n = s.members.size();
+        const size_t n = (size_t)s.member_count();
         if (n < 3) return;
         Moments m;
         const double fp = arc.f_peak;
+        const double *const mf = s.mem_f.data() + s.m_lo;
+        const double *const mx = s.mem_x.data() + s.m_lo;
+        const double *const my = s.mem_y.data() + s.m_lo;
         if (simd_) {
             double v[11];
-            simd_moments(s.mf.data(), s.mx.data(), s.my.data(), n, fp, v);
+            simd_moments(mf, mx, my, n, fp, v);
             m.T0 = v[0]; m.T1 = v[1]; m.T2 = v[2]; m.T3 = v[3]; m.T4 = v[4];
             m.X1 = v[5]; m.TX = v[6]; m.T2X = v[7];
             m.Y1 = v[8]; m.TY = v[9]; m.T2Y = v[10];
@@ -1214,8 +1370,8 @@ private:
             return;
         }
         for (size_t i = 0; i < n; ++i) {
-            const double t = s.mf[i] - fp;
-            const double x = s.mx[i], y = s.my[i];
+            const double t = mf[i] - fp;
+            const double x = mx[i], y = my[i];
             const double t2 = t * t;
             m.T0 += 1.0;
             m.T1 += t;
@@ -1232,170 +1388,216 @@ private:
         solve_fit(arc, m, rot_);
     }
 
+    // One pass over the frontier: drops the tags of frame `dead` (the frame
+    // the last new member took -- the only one that became taken; order is
+    // kept), computes every remaining tag's squared distance to the arc and
+    // finds the nearest: smallest distance, lowest tag index among equals.
+    // Compared on squared distances; roots are only taken among those within
+    // rounding of the smallest.  Returns the number of tags left, with the
+    // nearest one's position in `at` and its distance in `best_d`.  The first
+    // `known` tags have their squared distance to this arc in fr_q already
+    // (the arc has not been refitted since the last scan).
+    size_t scan_frontier(Scratch &s, const Arc &arc, double dead, size_t known,
+                         size_t &at, double &best_d) const {
+        const size_t nf = s.nf;
+        int *const id = s.fr_id.data();
+        double *const ff = s.fr_f.data(), *const fx = s.fr_x.data(),
+                     *const fy = s.fr_y.data(), *const fq = s.fr_q.data();
+        const double pa = arc.a, pb = arc.b, pc = arc.c, pe = arc.e,
+                     pf = arc.f_peak, rs = rot_.s, rc = rot_.c;
+        const double inf = std::numeric_limits<double>::infinity();
+        double q1 = inf, q2 = inf;      // smallest and second smallest
+        size_t i1 = 0, k = 0;
+        bool plain = true;              // no NaN met
+        for (size_t i = 0; i < nf; ++i) {
+            const double f = ff[i];
+            if (f == dead) continue;
+            const double x = fx[i], y = fy[i];
+            double q;
+            if (i < known) {
+                q = fq[i];
+            } else {    // the operations of dist_sq(), in its order
+                const double t = f - pf;
+                const double xj = pa + pb * t;
+                const double yj = pc + pe * t * t;
+                const double px = xj * rc + yj * rs;
+                const double py = yj * rc - xj * rs;
+                const double dx = px - x, dy = py - y;
+                q = dx * dx + dy * dy;
+            }
+            if (k != i) {
+                id[k] = id[i];
+                ff[k] = f;
+                fx[k] = x;
+                fy[k] = y;
+            }
+            fq[k] = q;
+            if (q < q1) {
+                q2 = q1;
+                q1 = q;
+                i1 = k;
+            } else if (q < q2) {
+                q2 = q;
+            } else if (q != q) {
+                plain = false;
+            }
+            ++k;
+        }
+        s.nf = k;
+        if (k == 0) return 0;
+        // nobody else within rounding of the smallest (nearly always)
+        if (plain && q2 > q1 * (1 + 1e-14)) {
+            at = i1;
+            best_d = std::sqrt(q1);
+            return k;
+        }
+        double q_min = 0;
+        for (size_t i = 0; i < k; ++i)
+            if (i == 0 || fq[i] < q_min) q_min = fq[i];
+        int best = -1;
+        best_d = 0;
+        if (q_min == q_min) {
+            const double q_tie = q_min * (1 + 1e-14);
+            for (size_t i = 0; i < k; ++i) {
+                if (!(fq[i] <= q_tie)) continue;
+                const double d = std::sqrt(fq[i]);
+                if (best < 0 || d < best_d || (d == best_d && id[i] < best)) {
+                    best = id[i];
+                    best_d = d;
+                    at = i;
+                }
+            }
+        }
+        if (best < 0) {         // NaN distances: the literal scan
+            for (size_t i = 0; i < k; ++i) {
+                const double d = std::sqrt(fq[i]);
+                if (best < 0 || d < best_d || (d == best_d && id[i] < best)) {
+                    best = id[i];
+                    best_d = d;
+                    at = i;
+                }
+            }
+        }
+        return k;
+    }
+
     // One seed: try its neighbours in order until one pair grows into an
     // acceptable arc (reference tracker.py:521-625).
     void run_seed(int t1, int pos, Scratch &s, SeedResult &res) {
+        s.consulted.clear();
+        grow_seed(t1, pos, s, res);
+        res.consulted.assign(s.consulted.begin(), s.consulted.end());
+    }
+
+    void grow_seed(int t1, int pos, Scratch &s, SeedResult &res) {
         const hk_clip &c = c_;
         res.made = false;
-        res.consulted.clear();
         ++s.run_stamp;
+        ++s.runs;
         Span nb1;
-        { S3P_T0; nb1 = neighbors(t1, s); S3P_ADD(5); }
+        S3P_SCOPE(11);
+        { S3P_T0(5); nb1 = neighbors(t1, s); S3P_ADD(5); }
+        const int f1 = c.frame[t1];
+        const double x1 = c.x[t1], y1 = c.y[t1];
         for (int t2 : nb1) {
             if (is_done(t2, pos)) continue;
             consult(t2, s, res);
-            S3P_CNT(7, 1);
+            S3P_SCOPE(10);
             ++s.stamp;
             Arc arc;
-            const int f1 = c.frame[t1], f2 = c.frame[t2];
-            // members in ascending tag order, with their coordinates alongside
-            std::vector<int> &members = s.members;
-            members.clear();
-            s.mf.clear();
-            s.mx.clear();
-            s.my.clear();
-            for (int j : {std::min(t1, t2), std::max(t1, t2)}) {
-                members.push_back(j);
-                s.mf.push_back((double)c.frame[j]);
-                s.mx.push_back(c.x[j]);
-                s.my.push_back(c.y[j]);
+            const int f2 = c.frame[t2];
+            const double x2 = c.x[t2], y2 = c.y[t2];
+            s.members_clear();
+            if (t1 < t2) {
+                s.member_insert(t1, (double)f1, x1, y1);
+                s.member_insert(t2, (double)f2, x2, y2);
+            } else {
+                s.member_insert(t2, (double)f2, x2, y2);
+                s.member_insert(t1, (double)f1, x1, y1);
             }
             s.taken[f1] = s.stamp;
             s.taken[f2] = s.stamp;
-            s.frontier.clear();
-            s.ff.clear();
-            s.fx.clear();
-            s.fy.clear();
-            { S3P_T0;
+            s.nf = 0;
+            { S3P_T0(0);
             add_neighbors_to_frontier(t1, pos, s, res);
             add_neighbors_to_frontier(t2, pos, s, res);
             S3P_ADD(0); }
 
             arc.e = e0_;
-            arc.f_peak = (c.y[t1] - c.y[t2]) / (2.0 * arc.e * (f2 - f1)) +
+            arc.f_peak = (y1 - y2) / (2.0 * arc.e * (f2 - f1)) +
                          0.5 * (f1 + f2);
             const double dt1 = f1 - arc.f_peak;
-            arc.c = c.y[t1] - arc.e * (dt1 * dt1);
-            arc.b = (c.x[t1] - c.x[t2]) / (f1 - f2);
-            arc.a = c.x[t1] - arc.b * (f1 - arc.f_peak);
+            arc.c = y1 - arc.e * (dt1 * dt1);
+            arc.b = (x1 - x2) / (f1 - f2);
+            arc.a = x1 - arc.b * (f1 - arc.f_peak);
 
             bool bad = false;
-            while (!s.frontier.empty()) {
+            double dead = -1.0;     // no frame: nothing to drop yet
+            size_t known = 0;       // frontier tags whose fr_q is up to date
+            while (s.nf > 0) {
+                size_t at = 0;
+                double best_d = 0;
+                S3P_CNT(6, s.nf);
+                {
+                    S3P_T0(1);
+                    const size_t left =
+                        scan_frontier(s, arc, dead, known, at, best_d);
+                    S3P_ADD(1);
+                    if (left == 0) break;
+                    known = left;
+                }
                 // an arc committed meanwhile took this seed: the committer
                 // will skip it, whatever this run would find
                 if (done_[t1].load(std::memory_order_relaxed)) return;
-                // nearest frontier tag: smallest distance, lowest index among
-                // equals.  Compared on squared distances; the roots are only
-                // taken among those within rounding of the smallest.
-                const size_t nf = s.frontier.size();
-                S3P_CNT(6, nf);
-                S3P_T0;
-                s.fq.resize(nf);
-                double q_min = 0;
-                if (simd_) {
-                    const double p5[5] = {arc.a, arc.b, arc.c, arc.e,
-                                          arc.f_peak};
-                    simd_dist_sq(p5, rot_.s, rot_.c, s.ff.data(), s.fx.data(),
-                                 s.fy.data(), nf, s.fq.data());
-                    for (size_t i = 0; i < nf; ++i)
-                        if (i == 0 || s.fq[i] < q_min) q_min = s.fq[i];
-                } else {
-                    for (size_t i = 0; i < nf; ++i) {
-                        const double q =
-                            dist_sq(arc, s.ff[i], s.fx[i], s.fy[i]);
-                        s.fq[i] = q;
-                        if (i == 0 || q < q_min) q_min = q;
-                    }
-                }
-                int best = -1;
-                double best_d = 0;
-                if (q_min == q_min) {
-                    const double q_tie = q_min * (1 + 1e-14);
-                    for (size_t i = 0; i < nf; ++i) {
-                        if (!(s.fq[i] <= q_tie)) continue;
-                        const int j = s.frontier[i];
-                        const double d = std::sqrt(s.fq[i]);
-                        if (best < 0 || d < best_d ||
-                            (d == best_d && j < best)) {
-                            best = j;
-                            best_d = d;
-                        }
-                    }
-                }
-                if (best < 0) {         // NaN distances: the literal scan
-                    for (size_t i = 0; i < nf; ++i) {
-                        const int j = s.frontier[i];
-                        const double d = std::sqrt(s.fq[i]);
-                        if (best < 0 || d < best_d ||
-                            (d == best_d && j < best)) {
-                            best = j;
-                            best_d = d;
-                        }
-                    }
-                }
-                S3P_ADD(1);
                 if (best_d > maxd_) break;
-                const size_t at = (size_t)(
-                    std::upper_bound(members.begin(), members.end(), best) -
-                    members.begin());
-                const TagRec &tb = tag_[(size_t)best];
-                members.insert(members.begin() + (long)at, best);
-                s.mf.insert(s.mf.begin() + (long)at, (double)tb.frame);
-                s.mx.insert(s.mx.begin() + (long)at, tb.x);
-                s.my.insert(s.my.begin() + (long)at, tb.y);
-                s.taken[tb.frame] = s.stamp;
-                if (doomed(s)) {
+                ++s.steps;
+                const int best = s.fr_id[at];
+                const double fb = s.fr_f[at];       // its frame
+                bool is_doomed;
+                {
+                    S3P_SCOPE(8);
+                    s.member_insert(best, fb, s.fr_x[at], s.fr_y[at]);
+                    s.taken[(size_t)(int)fb] = s.stamp;
+                    is_doomed = doomed(s);
+                }
+                if (is_doomed) {
+                    S3P_END(1, s.member_count());
                     bad = true;
                     break;
                 }
-                { S3P_T0;
+                { S3P_T0(2);
                 add_neighbors_to_frontier(best, pos, s, res);
                 S3P_ADD(2); }
-                {   // drop the frontier tags of the frame just taken (the
-                    // only frame that became taken; order is kept)
-                    const double fb = (double)tb.frame;
-                    const size_t nfr = s.frontier.size();
-                    size_t k = 0;
-                    for (size_t i = 0; i < nfr; ++i) {
-                        if (s.ff[i] == fb) continue;
-                        if (k != i) {
-                            s.frontier[k] = s.frontier[i];
-                            s.ff[k] = s.ff[i];
-                            s.fx[k] = s.fx[i];
-                            s.fy[k] = s.fy[i];
-                        }
-                        ++k;
-                    }
-                    s.frontier.resize(k);
-                    s.ff.resize(k);
-                    s.fx.resize(k);
-                    s.fy.resize(k);
-                }
+                dead = fb;      // dropped by the next scan
                 bool refit = false;
-                if ((int)members.size() > c.p.min_tags_to_curve_fit) {
-                    S3P_T0;
+                if (s.member_count() > c.p.min_tags_to_curve_fit) {
+                    S3P_T0(3);
                     fit_members(arc, s);
                     S3P_ADD(3);
                     refit = true;
+                    known = 0;
                 }
                 if (std::isnan(arc.e) || arc.e <= 0) {
+                    S3P_END(2, s.member_count());
                     bad = true;
                     break;
                 }
                 if (refit) {
-                    S3P_T0;
-                    const size_t nm = members.size();
+                    S3P_T0(4);
+                    const size_t nm = (size_t)s.member_count();
+                    const double *const mf = s.mem_f.data() + s.m_lo;
+                    const double *const mx = s.mem_x.data() + s.m_lo;
+                    const double *const my = s.mem_y.data() + s.m_lo;
                     if (simd_) {
                         const double p5[5] = {arc.a, arc.b, arc.c, arc.e,
                                               arc.f_peak};
-                        bad = simd_any_farther(p5, rot_.s, rot_.c,
-                                               s.mf.data(), s.mx.data(),
-                                               s.my.data(), nm, maxd_,
-                                               maxd_sq_lo_, maxd_sq_hi_);
+                        bad = simd_any_farther(p5, rot_.s, rot_.c, mf, mx, my,
+                                               nm, maxd_, maxd_sq_lo_,
+                                               maxd_sq_hi_);
                     } else {
                         for (size_t i = 0; i < nm; ++i)
                             if (farther_than_maxd(
-                                    dist_sq(arc, s.mf[i], s.mx[i], s.my[i]))) {
+                                    dist_sq(arc, mf[i], mx[i], my[i]))) {
                                 bad = true;
                                 break;
                             }
@@ -1405,17 +1607,25 @@ private:
                 // without a refit the arc is unchanged: the older members
                 // passed this test already and the new one has
                 // best_d <= maxd
-                if (bad) break;
+                if (bad) {
+                    S3P_END(3, s.member_count());
+                    break;
+                }
             }
             // eval_arc() fails with fewer than min_tags_per_arc members
             // whatever else holds: skip the call
-            if (!bad && (int)members.size() >= c.p.min_tags_per_arc) {
-                arc.tags = members;
+            if (!bad && s.member_count() >= c.p.min_tags_per_arc) {
+                arc.tags.assign(s.mem_id.data() + s.m_lo,
+                                s.mem_id.data() + s.m_hi);
                 if (eval_arc_host(c, arc, rot_, false, true) == 0) {
+                    S3P_END(6, s.member_count());
                     res.arc = std::move(arc);
                     res.made = true;
                     return;
                 }
+                S3P_END(5, s.member_count());
+            } else if (!bad) {
+                S3P_END(s.member_count() == 2 ? 0 : 4, s.member_count());
             }
         }
     }
@@ -1424,7 +1634,7 @@ private:
         double x, y;
         int frame, qpos;
     };
-    std::vector<TagRec> tag_;
+    alignas(128) std::vector<TagRec> tag_;
 
     hk_clip &c_;
     const int n_;
@@ -2096,20 +2306,31 @@ extern "C" int hk_clip_build_initial_arcs(hk_clip *c) {
             fprintf(stderr,
                     "step3: set-up %.1f ms, trial pass %.1f ms, full pass %.1f ms (%ld stale "
                     "results recomputed in %.1f ms, committer ran %ld seeds, "
-                    "seed time summed over threads %.1f ms; device results "
-                    "used %ld, handed back %ld)\n",
+                    "seed time summed over threads %.1f ms, %ld seeds run, %ld "
+                    "growth steps; device results used %ld, handed back %ld)\n",
                     ms(t0, t_built), ms(t_built, t1), ms(t1, now()),
                     b.stat_stale_, b.stat_stale_ms_,
-                    b.stat_helped_, b.stat_busy_ms_, b.stat_dev_used_.load(),
+                    b.stat_helped_, b.stat_busy_ms_, b.stat_runs_,
+                    b.stat_steps_, b.stat_dev_used_.load(),
                     b.stat_dev_host_.load());
 #ifdef HK_S3_PROF
         if (stats) {
-            static const char *nm[8] = {"frontier init", "distance scan + min",
+            static const char *nm[12] = {"frontier init", "distance scan + min",
                 "frontier add (growth)", "fit", "member check", "seed nb list",
-                "nb list builds (cyc) / frontier tags scanned (n)", "trials"};
-            for (int k = 0; k < 8; ++k)
+                "frontier tags scanned (n)", "-", "insert + doomed",
+                "frontier compaction", "whole trial", "whole seed"};
+            for (int k = 0; k < 12; ++k)
                 fprintf(stderr, "  s3prof %-24s %8.2f Mcyc  n=%llu\n", nm[k],
                         hk::g_s3prof.cyc[k] / 1e6, hk::g_s3prof.cnt[k]);
+            static const char *en[7] = {"no tag near", "doomed", "e <= 0",
+                "member too far", "too few members", "eval_arc no", "accepted"};
+            for (int k = 0; k < 7; ++k) {
+                fprintf(stderr, "  s3prof end %-16s trials %7llu steps %7llu  by size <4,<8,..:",
+                        en[k], hk::g_s3prof.end_n[k], hk::g_s3prof.end_steps[k]);
+                for (int h = 0; h < 8; ++h)
+                    fprintf(stderr, " %llu", hk::g_s3prof.hist[k][h]);
+                fprintf(stderr, "\n");
+            }
             hk::g_s3prof = hk::S3Prof();
         }
 #endif
