@@ -97,6 +97,44 @@ def test_static_scratch_entry_point_equals_the_allocating_one():
     compare(12, 18, 48, 64, [(0, 18)])
     # and an odd geometry (general kernel), smaller again
     compare(13, 9, 37, 53, [(0, 9)])
+    # continuing batches on the odd geometry, then back to the tiled one on
+    # the same stream: the costs in the array belong to another kernel's units
+    compare(14, 20, 37, 53, [(0, 7), (7, 20)])
+    compare(15, 12, 96, 128, [(0, 5), (5, 12)])
+
+
+def test_static_scratch_entry_point_takes_no_device_memory():
+    """Its defining property: after the first call on the device (which looks
+    the array's address up) no call changes the amount of free device memory,
+    whatever the geometry -- a hipMalloc inside would, cached or not."""
+    from hawkeye_amd import _native as nat
+    rng = np.random.RandomState(21)
+    shapes = [(24, 48, 64), (16, 96, 128), (9, 37, 53), (6, 270, 480)]
+    inputs = []
+    for t, h, w in shapes:          # every torch allocation up front
+        frames = torch.from_numpy(frames_moving(rng, t, h, w)).cuda()
+        inputs.append((frames, torch.zeros((40, w * h), dtype=torch.float32,
+                                           device='cuda'),
+                       torch.empty(frames.shape[:3], dtype=torch.uint8,
+                                   device='cuda')))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(k, first):
+        frames, model, masks = inputs[k]
+        t, h, w = shapes[k]
+        nat.check(nat.lib.hk_mog_apply_batch_static(
+            w, h, 0, model.data_ptr(), first, frames.data_ptr(),
+            frames.stride(0), frames.stride(1), masks.data_ptr(),
+            masks.stride(0), masks.stride(1), t, stream))
+
+    run(0, 0)                       # first call on the device
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for rep in range(3):
+        for k in range(len(shapes)):
+            run(k, rep * shapes[k][0])
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
 
 
 def test_static_scratch_entry_point_rejects_frames_beyond_its_maximum():
