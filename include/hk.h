@@ -125,7 +125,14 @@ int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
  * Every call on a GPU shares that GPU's array, which keeps the previous
  * call's contents: the call re-initialises what it reads, but calls that
  * OVERLAP on one GPU (two host threads, or two streams with both launches in
- * flight) race on it.  The first call on a device looks the array's device
+ * flight) race on it, and that race can CORRUPT RESULTS, not just the launch
+ * order: a batch kernel takes its pixel groups from the order list, and if a
+ * call on another stream rewrites that list for its own geometry between
+ * this call's ordering pass and its batch kernel, groups are skipped or
+ * stepped twice.  (Within one call the list is always a permutation, whatever
+ * happens to the costs it is made from; the learning-rate table is rewritten
+ * with the same values by every call.)  Serialise the calls on a device, e.g.
+ * by keeping them on one stream.  The first call on a device looks the array's device
  * address up (hipGetSymbolAddress); make that call outside stream capture.
  * Enqueues on `stream`. */
 int hk_mog_apply_batch_static(int width, int height, int device,
