@@ -1,3 +1,8 @@
+"""Step 3 of the benchmark clip's events on one thread with two builds of the library in turn
+(HK_NATIVE_LIB), the CPU time of the build call, best of five per round: how DESIGN.md's
+"92 -> 84 ms" was measured.  Run from the repository root, on the machine that counts:
+    python3 tools/probe/s3_ab.py <old libhawkeye_hip.so> <new libhawkeye_hip.so> [rounds]
+(an older build: `git stash` or a worktree, `make -C hawkeye_amd/csrc`, copy the library away)."""
 import os, sys, time, subprocess
 # alternate old/new, single thread, CPU time of the build call, min over reps
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
