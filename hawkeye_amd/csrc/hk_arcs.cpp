@@ -1143,13 +1143,19 @@ private:
                 if (g == f) continue;
                 const int df = std::abs(g - f);
                 const double r = v_max_ * df * (1 + 1e-12) + 1e-9;
+                // farther than this (squared) is beyond the cap whatever the
+                // root and the division round to: most tags of the x-window
+                // are, and need neither
+                const double far_sq = (v_max_ * df) * (v_max_ * df) * (1 + 1e-9);
                 const double *xb = xs_val_.data() + c.start[g];
                 const double *xe = xs_val_.data() + c.start[g + 1];
                 for (const double *p = std::lower_bound(xb, xe, xi - r);
                      p < xe && *p <= xi + r; ++p) {
                     const int j = xs_idx_[(size_t)(p - xs_val_.data())];
                     const double dx = c.x[j] - xi, dy = c.y[j] - yi;
-                    const double v = std::sqrt(dx * dx + dy * dy) / df;
+                    const double q = dx * dx + dy * dy;
+                    if (q > far_sq) continue;
+                    const double v = std::sqrt(q) / df;
                     if (!(v <= v_max_)) continue;
                     s.cand.push_back(j);
                     s.vel.push_back(v);
