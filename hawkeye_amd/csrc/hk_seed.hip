@@ -685,6 +685,7 @@ struct SeedDevice {
     hk_clip *clip = nullptr;
     SeedParams prm;
     int n = 0, window = 0, windows = 0;
+    bool opened_own = false;    // the clip's own EM batch was opened here
 };
 
 void seed_release_cached() {
@@ -698,6 +699,7 @@ void seed_release_cached() {
 
 void seed_close(SeedDevice *sd) {
     if (!sd) return;
+    if (sd->opened_own && sd->clip) em_release(*sd->clip);
     if (sd->ws) {
         std::lock_guard<std::mutex> lock(g_ws_mutex);
         if (g_ws_pool.size() < 8) {
@@ -797,10 +799,15 @@ int seed_open(hk_clip &c, const SeedParams &prm, const std::vector<int> &queue,
     if (!w->event)
         S3_HIP(hipEventCreateWithFlags(&w->event, hipEventDisableTiming |
                                                       hipEventBlockingSync));
-    // tags (shared with step 4), frame index, seed order
+    // tags (in the clip's own EM batch of one, released again when the
+    // device side closes: step 4 opens the batch it wants), frame index, seed
+    // order
     {
-        const int rc = em_prepare(c, s);
+        const bool had_own = c.own != nullptr;
+        EmBatch *own = nullptr;
+        const int rc = em_own(c, s, &own);
         if (rc != HK_OK) return bail(rc);
+        sd->opened_own = !had_own;
     }
     S3_HIP(hipMemcpyAsync(w->start, c.start.data(), sizeof(int) * (c.F + 1),
                           hipMemcpyHostToDevice, s));
@@ -809,7 +816,8 @@ int seed_open(hk_clip &c, const SeedParams &prm, const std::vector<int> &queue,
     S3_HIP(hipMemcpyAsync(w->qpos, qpos.data(), sizeof(int) * c.n,
                           hipMemcpyHostToDevice, s));
     S3_HIP(hipMemsetAsync(w->flags, 0, 64, s));
-    const Tags tg{c.dev.frame, c.dev.x, c.dev.y, w->start, c.n, c.F};
+    const Tags tg{c.own->dev.frame, c.own->dev.x, c.own->dev.y, w->start, c.n,
+                  c.F};
     hipLaunchKernelGGL(seed_neighbors_k, dim3((unsigned)c.n), dim3(64), 0, s,
                        tg, prm.gap, prm.has_vmax, prm.v_max, w->nb, w->nb_len,
                        w->flags);
@@ -864,7 +872,8 @@ int seed_round(SeedDevice *sd, int index, const unsigned char *done,
     io.made_params = (double *)(made + lay.m_params);
     io.made_n = (int *)(made + lay.m_n);
     io.made_members = (int *)(made + lay.m_members);
-    const Tags tg{c.dev.frame, c.dev.x, c.dev.y, w->start, c.n, c.F};
+    const Tags tg{c.own->dev.frame, c.own->dev.x, c.own->dev.y, w->start, c.n,
+                  c.F};
     hipLaunchKernelGGL(seed_run_k, dim3((unsigned)count), dim3(64), 0, s, tg,
                        sd->prm, io);
     HK_LAUNCH_CHECK("seed_run_k");

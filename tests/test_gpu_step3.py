@@ -3,7 +3,17 @@ GPU: step 3 with its seeds evaluated on the device (hk_seed.hip, through the
 C ABI) against the host code path, bit for bit: same arcs, same members, same
 parameters; with the library's self check on, every single seed's device
 result is compared with the host's.
+
+The product library is built without the device side (it is the slower path);
+`make DEVICE_SEEDS=1` builds hawkeye_amd/libhawkeye_hip_device_seeds.so with
+it.  With the product library loaded the cases below skip, and
+test_device_side_in_its_own_library runs this file once more in a child
+process that loads the other library (HK_NATIVE_LIB).
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -32,7 +42,8 @@ def build(monkeypatch, geometry, soa, device, window=None, self_check=False):
     from hawkeye_amd.arcs import Clip
     if device and not nat.lib.hk_step3_device_built():
         pytest.skip('library built without the opt-in device side of step 3 '
-                    '(make -C hawkeye_amd/csrc DEVICE_SEEDS=1)')
+                    '(make -C hawkeye_amd/csrc DEVICE_SEEDS=1, then '
+                    'HK_NATIVE_LIB=hawkeye_amd/libhawkeye_hip_device_seeds.so)')
     width, height, fps, frames = geometry
     frame, x, y, r, tw, start = soa
     monkeypatch.setenv('HK_STEP3_DEVICE', '2' if device else '0')
@@ -85,3 +96,23 @@ def test_device_path_on_golden_run(monkeypatch, golden_dir):
     dev = build(monkeypatch, geometry, soa, device=True, self_check=True)
     assert dev == host
     assert len(dev[2]) == len(run['step3']['arcs'])
+
+
+def test_device_side_in_its_own_library():
+    from hawkeye_amd import _native as nat
+    if nat.lib.hk_step3_device_built():
+        pytest.skip('this process has the device side loaded: the cases above ran')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = os.path.join(repo, 'hawkeye_amd', 'libhawkeye_hip_device_seeds.so')
+    if not os.path.exists(other):
+        pytest.skip('hawkeye_amd/libhawkeye_hip_device_seeds.so is not built '
+                    '(make -C hawkeye_amd/csrc DEVICE_SEEDS=1)')
+    env = dict(os.environ, HK_NATIVE_LIB=other)
+    out = subprocess.run(
+        [sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x',
+         '-m', 'gpu', '-p', 'no:cacheprovider',
+         '--deselect', 'tests/test_gpu_step3.py::test_device_side_in_its_own_library'],
+        cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    tail = out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    assert ' passed' in out.stdout and 'skipped' not in out.stdout.splitlines()[-1], tail
