@@ -37,11 +37,13 @@
 
 #include "hk_seed.h"
 
-// Build option: `make DEVICE_SEEDS=0` leaves the device side of step 3 out of
-// the library (it is opt-in at run time anyway, HK_STEP3_DEVICE, and the
-// multi-thread host builder is the faster one on every clip measured so
-// far).  seed_open() then reports "does not apply here" and hk_arcs.cpp takes
-// its host path, as it does for a clip the fixed-size device lists cannot hold.
+// Build option: the product library (`make`, i.e. DEVICE_SEEDS=0) leaves the
+// device side of step 3 out: it is opt-in at run time anyway, HK_STEP3_DEVICE,
+// and the multi-thread host builder is the faster one on every clip measured
+// so far.  seed_open() then reports "does not apply here" and hk_arcs.cpp
+// takes its host path, as it does for a clip the fixed-size device lists
+// cannot hold.  `make DEVICE_SEEDS=1` builds libhawkeye_hip_device_seeds.so
+// with it (select with HK_NATIVE_LIB; tests/test_gpu_step3.py).
 #ifdef HK_NO_DEVICE_SEEDS
 extern "C" int hk_step3_device_built(void) { return 0; }
 namespace hk {

@@ -329,9 +329,10 @@ int hk_clip_build_initial_arcs(hk_clip *c);
 int hk_step3_help(int max_seeds);
 
 /* 1 if this build of the library contains the opt-in device side of step 3
- * (hk_seed.hip; `make DEVICE_SEEDS=1`, selected at run time with
- * HK_STEP3_DEVICE=1|2), 0 for the default build, in which step 3 is host code
- * only.  Either way the arcs are the same.  No counterpart in the reference. */
+ * (hk_seed.hip; `make DEVICE_SEEDS=1` builds it as a second library,
+ * libhawkeye_hip_device_seeds.so; selected at run time with
+ * HK_STEP3_DEVICE=1|2), 0 for the product library, in which step 3 is host
+ * code only.  Either way the arcs are the same.  No counterpart in the reference. */
 int hk_step3_device_built(void);
 
 /* Host threads step 3 may use: 0 = automatic (the smaller of the hardware
