@@ -52,8 +52,9 @@ int hk_version(void);
 /* Number of HIP devices visible, or a negative status. */
 int hk_device_count(void);
 
-/* Destroyed clips park their device workspace (a few MB) for the next clip on
- * the same device instead of freeing it; this frees what is parked. */
+/* A finished EM batch (hk_clip_em_optimize, hk_clips_em_optimize) parks its
+ * device workspace (a few MB) for the next batch on the same device instead
+ * of freeing it; this frees what is parked. */
 int hk_release_cached_memory(void);
 
 /* ------------------------------------------------------------------------
@@ -132,8 +133,9 @@ int hk_mog_apply_batch_tiles(hk_mog *m, const void *bgr_dev,
  * stepped twice.  (Within one call the list is always a permutation, whatever
  * happens to the costs it is made from; the learning-rate table is rewritten
  * with the same values by every call.)  Serialise the calls on a device, e.g.
- * by keeping them on one stream.  The first call on a device looks the array's device
- * address up (hipGetSymbolAddress); make that call outside stream capture.
+ * by keeping them on one stream.
+ * The first call on a device looks the array's device address up
+ * (hipGetSymbolAddress); make that call outside stream capture.
  * Enqueues on `stream`. */
 int hk_mog_apply_batch_static(int width, int height, int device,
                               void *model_dev, int frames_before,
